@@ -1,0 +1,185 @@
+/*
+ * rt_hip.h -- C ABI of the MI355X ray-tracing core (librt_hip.so).
+ *
+ * This is the boundary a RayTrace host program binds instead of the reference's disabled
+ * CUDA offload (cuda_raytrace.h:10-13, kdtree.cuh:6-12).  Plain C: pointers, sizes and POD
+ * structs only.  Every function returns 0 on success or a negative RT_E_* code; the message
+ * for the calling thread's last failure is available from rt_last_error().
+ *
+ * Image axes follow the reference: x is the ROW and sizex the number of rows, y is the
+ * COLUMN and sizey the number of columns (raytrace.cpp:36, 217).
+ *
+ * Primitive ids reported by this library:
+ *     triangle : global id = (triangles of all earlier objects) + face index  (cuda.cu:80,158-159)
+ *     sphere   : -1 - sphere index
+ *     miss     : RT_ID_MISS
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_E_INVALID (-1)  /* bad argument / inconsistent scene description */
+#define RT_E_DEVICE (-2)   /* HIP runtime error */
+#define RT_E_NOMEM (-3)
+#define RT_E_LIMIT (-4)    /* a size exceeds what the kernels are built for */
+
+#define RT_ID_MISS INT32_MIN
+
+/* Material types, point.h:9 */
+#define RT_DIFF 0
+#define RT_SPEC 1
+#define RT_REFR 2
+
+/*
+ * Flattened scene, produced on the host (librt_host.so: rth_scene_desc) from the reference's
+ * data model: vector<Object> of Polygons, vector<Sphere>, KdTree.  All arrays stay owned by the
+ * caller and are only read during rt_upload_scene.
+ *
+ * Nodes are in PRE-ORDER (node, left subtree, right subtree) -- the order of the reference's own
+ * flattening, travKdTree (cuda.cu:68-89) -- so a left child, when present, is always node+1.
+ * Own lists (KdTree::node) are concatenated in the same order; every triangle appears in exactly
+ * one own list because straddling triangles stay on the interior node (kdtree.cpp:85-93).
+ */
+typedef struct rt_scene_desc {
+    int32_t n_nodes;           /* >= 1: an empty scene still has the empty root leaf */
+    const double *node_box;    /* [n_nodes][6]  mi.xyz, ma.xyz      KdTree::aabb  (kdtree.cpp:34-35) */
+    const double *node_split;  /* [n_nodes]     KdTree::split       (kdtree.cpp:82); unused for leaves */
+    const int32_t *node_axis;  /* [n_nodes]     KdTree::w           (kdtree.cpp:33) */
+    const int32_t *node_left;  /* [n_nodes]     index or -1         KdTree::l */
+    const int32_t *node_right; /* [n_nodes]     index or -1         KdTree::r */
+    const int32_t *node_first; /* [n_nodes]     first own-list entry */
+    const int32_t *node_count; /* [n_nodes]     own-list length     KdTree::node.size() */
+    int32_t n_list;            /* total own-list entries, == n_tris */
+    const int32_t *list_tri;   /* [n_list]      global triangle ids */
+    int32_t tree_depth;        /* nodes on the longest root-to-leaf path */
+
+    int32_t n_tris;
+    const double *tri_verts;   /* [n_tris][9]   Polygon::points3d */
+    const double *tri_nc;      /* [n_tris][3]   Polygon::nc         (polygon.h:23-27) */
+    const double *tri_col;     /* [n_tris][3]   Polygon::col        (getcol, untextured: polygon.h:75) */
+    const double *tri_lig;     /* [n_tris][3]   owning Object::lig  (raytrace.cpp:66) */
+    const int32_t *tri_type;   /* [n_tris]      owning Object::type (raytrace.cpp:66) */
+
+    int32_t n_spheres;
+    const double *sph_rad;     /* [n_spheres]    Sphere::rad */
+    const double *sph_pos;     /* [n_spheres][3] Sphere::pos */
+    const double *sph_lig;     /* [n_spheres][3] Sphere::lig */
+    const double *sph_col;     /* [n_spheres][3] Sphere::col */
+    const int32_t *sph_type;   /* [n_spheres]    Sphere::type */
+} rt_scene_desc;
+
+/* Camera as the scene file gives it (raytrace.cpp:148-151); the basis vectors cx, cy and the
+ * normalised direction are derived inside the library exactly as raytrace.cpp:155-156 does. */
+typedef struct rt_camera {
+    double o[3];
+    double d[3];
+    int32_t sizex; /* rows */
+    int32_t sizey; /* columns */
+} rt_camera;
+
+/* Rows [x0, x0+rows) x columns [y0, y0+cols) of the image. */
+typedef struct rt_tile {
+    int32_t x0, y0, rows, cols;
+} rt_tile;
+
+/*
+ * Integrator controls.  reference behaviour = {samps, 5, 1, 2, <large>, 1, seed}.
+ *   rr_depth    Russian roulette starts once ++depth > rr_depth       (raytrace.cpp:70; reference 5)
+ *   rr_mode     1: roulette with survival probability max(f)          (raytrace.cpp:71-74)
+ *               0: the path ends there and returns the emission -- a hard depth bound
+ *   split_depth glass traces BOTH branches while depth <= split_depth (raytrace.cpp:93; reference 2), max 4
+ *   hard_depth  the path ends once ++depth > hard_depth; the reference recursion has no such bound
+ *   jitter      1: tent-filter sub-pixel jitter from two draws        (raytrace.cpp:200-201)
+ *               0: dx = dy = 0 and no draws are consumed
+ *   seed        every path (pixel, sub-pixel, sample) restarts the drand48 recurrence from a state
+ *               hashed from (seed, path index), so results do not depend on tiling or GPU count
+ */
+typedef struct rt_params {
+    int32_t samps;
+    int32_t rr_depth;
+    int32_t rr_mode;
+    int32_t split_depth;
+    int32_t hard_depth;
+    int32_t jitter;
+    uint64_t seed;
+} rt_params;
+
+/* Work counters. A ray is one nearest-hit query = one radiance() invocation of the reference. */
+typedef struct rt_stats {
+    uint64_t rays;        /* radiance() invocations            (raytrace.cpp:41) */
+    uint64_t node_visits; /* KdTree::check invocations         (kdtree.cpp:111) */
+    uint64_t tri_tests;   /* Polygon::intersect in check_node  (kdtree.cpp:105) */
+    uint64_t sph_tests;   /* Sphere::intersect                 (sphere.cpp:8) */
+} rt_stats;
+
+typedef struct rt_scene rt_scene; /* opaque, one per (scene, device) */
+
+/* replaces check_device() (cuda_raytrace.h:10, device_query.cu:5-14): number of GPUs, or <0 */
+int rt_device_count(void);
+
+/* replaces print_device_info() (cuda_raytrace.h:11, device_query.cu:16-64): writes a
+ * NUL-terminated description of device `dev` into buf (at most cap bytes) */
+int rt_device_info(int dev, char *buf, size_t cap);
+
+/* replaces cudaSetDevice + cudaDeviceSetLimit + copyToDevice (raytrace.cpp:165-171,
+ * cuda_raytrace.h:12, cuda.cu:91-176): validates desc, lays the scene out in HBM on device `dev` */
+int rt_upload_scene(int dev, const rt_scene_desc *desc, rt_scene **out);
+
+int rt_free_scene(rt_scene *s);
+
+/*
+ * replaces the per-pixel cuda_radiance() loop (cuda_raytrace.h:13, raytrace.cpp:186-192,
+ * cuda.cu:412-427) for a whole tile: one kernel launch, synchronous, HOST output buffers.
+ *   rgb_out     [rows*cols*3] linear colour after the per-sub-pixel clamp and *0.25 average,
+ *               i.e. the value the reference accumulates into col[] (raytrace.cpp:205)
+ *   prim_id_out optional [rows*cols]: primitive hit by the pixel's first camera ray
+ *               (sub-pixel 0,0, sample 0)
+ *   stats       optional
+ */
+int rt_render_tile(rt_scene *s, const rt_camera *cam, const rt_tile *tile, const rt_params *p,
+                   double *rgb_out, int32_t *prim_id_out, rt_stats *stats);
+
+/*
+ * Same work for a list of tiles in ONE launch with DEVICE output buffers, asynchronous on
+ * `stream` (a hipStream_t, NULL = default stream).  Tile k's pixels are written contiguously
+ * (row-major inside the tile) starting at pixel offset sum_{j<k} rows_j*cols_j, so a GPU's share
+ * of the frame is one packed buffer ready for a gather.  d_prim_id may be NULL.
+ * Work counters of the launch are fetched with rt_get_stats (which synchronises the stream).
+ * Calls on one rt_scene must not overlap; different rt_scene objects are independent.
+ */
+int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int32_t n_tiles,
+                           const rt_params *p, double *d_rgb, int32_t *d_prim_id, void *stream);
+
+int rt_get_stats(rt_scene *s, rt_stats *stats);
+
+/* Milliseconds the last render kernel of this scene took on its stream (HIP events recorded
+ * around the launch); synchronises on the closing event. */
+int rt_last_kernel_ms(rt_scene *s, float *ms);
+
+/*
+ * Nearest-hit queries for explicit rays (6 doubles each: origin, direction) -- the pair of calls
+ * at raytrace.cpp:46-47, KdTree::check and sphere_intersect.  Host buffers, synchronous.
+ *   tri_id/tri_t  global triangle id or -1, and the distance the query left behind (1e20 on a miss)
+ *   sph_id/sph_t  sphere index or -1, and its distance (1e20 on a miss)
+ */
+int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, double *tri_t,
+                  int32_t *sph_id, double *sph_t, rt_stats *stats);
+
+/* IEEE-754 check of the device's double-precision divide (op 0: a/b) and square root (op 1:
+ * sqrt(a)), the only non-trivial operations bit-exact ids depend on.  Host buffers. */
+int rt_debug_fp64(int dev, int op, int64_t n, const double *a, const double *b, double *out);
+
+/* Message for the calling thread's most recent failing call ("" if none). */
+const char *rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

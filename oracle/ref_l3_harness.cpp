@@ -1,0 +1,167 @@
+// ref_l3_harness.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Thin extern "C" shim over the REFERENCE's own acceleration / intersection layer.
+// It is compiled together with the reference's kdtree.cpp and sphere.cpp *where they
+// lie* (see oracle/Makefile: -I$(REF), sources named by path, nothing copied), against
+// the CUDA runtime headers that ship inside this image's triton package -- point.h,
+// polygon.h and kdtree.h include <cuda.h>/<cuda_runtime.h> only for the
+// __host__/__device__ qualifiers.  The result, oracle/_ref/libref_l3.so, is the real
+// reference object code for:
+//     KdTree::KdTree / create      (kdtree.cpp:6-96)
+//     KdTree::check / check_node   (kdtree.cpp:98-142)
+//     KdTreeNode::check_aabb       (kdtree.h:57-76)
+//     Polygon ctor (nc) / intersect / getn   (polygon.h:17-72)
+//     Sphere::intersect, sphere_intersect    (sphere.h:13-21, sphere.cpp:3-14)
+//     Point3D / Ray                          (point.h)
+// raytrace.cpp (radiance, main) is NOT part of this build: it needs mpi.h and OpenCV,
+// which the image lacks.
+#include <vector>
+#include <cstring>
+#include "point.h"
+#include "polygon.h"
+#include "object.h"
+#include "sphere.h"
+#include "kdtree.h"
+
+struct RefScene {
+    std::vector<Object> objs;
+    std::vector<Sphere> spheres;
+    KdTree *tree;
+    RefScene() : tree(NULL) {}
+};
+
+static Ray mkray(const double *r) { return Ray(Point3D(r[0], r[1], r[2]), Point3D(r[3], r[4], r[5])); }
+
+extern "C" {
+
+void *ref_new() { return new RefScene(); }
+void ref_free(void *h) { delete (RefScene *)h; } // the reference's tree is never freed (kdtree.h:111-115)
+
+// One Object with ntri Polygons built by the reference's Polygon constructor.
+// vnormals (9 doubles per triangle) may be NULL -> zeros, texture is always NULL.
+int ref_add_object(void *h, const double *verts, int ntri, const double *lig, const double *col,
+                   const double *tri_cols, const double *vnormals, int type) {
+    RefScene *s = (RefScene *)h;
+    s->objs.push_back(Object());
+    Object &o = s->objs.back();
+    o.lig = Point3D(lig[0], lig[1], lig[2]);
+    o.col = Point3D(col[0], col[1], col[2]);
+    o.type = (RType)type;
+    for (int i = 0; i < ntri; i++) {
+        Point3D p[3], n[3], ts[3];
+        for (int k = 0; k < 3; k++) {
+            p[k] = Point3D(verts[9 * i + 3 * k], verts[9 * i + 3 * k + 1], verts[9 * i + 3 * k + 2]);
+            // the constructor stores n_[k] - points3d_[k]; pass p[k] itself for "no normals" so
+            // the stored value is exactly zero, as for a mesh whose loader gave none
+            n[k] = vnormals ? Point3D(vnormals[9 * i + 3 * k], vnormals[9 * i + 3 * k + 1], vnormals[9 * i + 3 * k + 2]) : p[k];
+        }
+        Point3D c = tri_cols ? Point3D(tri_cols[3 * i], tri_cols[3 * i + 1], tri_cols[3 * i + 2]) : o.col;
+        o.polys.push_back(Polygon(p, n, ts, o.lig, c, o.type, NULL, 0, 0));
+    }
+    return (int)s->objs.size() - 1;
+}
+
+int ref_add_sphere(void *h, double rad, const double *pos, const double *lig, const double *col, int type) {
+    RefScene *s = (RefScene *)h;
+    s->spheres.push_back(Sphere(rad, Point3D(pos[0], pos[1], pos[2]), Point3D(lig[0], lig[1], lig[2]),
+                                Point3D(col[0], col[1], col[2]), (RType)type));
+    return (int)s->spheres.size() - 1;
+}
+
+void ref_build(void *h) { // raytrace.cpp:128
+    RefScene *s = (RefScene *)h;
+    s->tree = new KdTree(s->objs, 0);
+}
+
+// KdTree::check (raytrace.cpp:46). Returns the bool; no/nv/t are what the call left behind.
+int ref_check(void *h, const double *ray, int *no, int *nv, double *t) {
+    RefScene *s = (RefScene *)h;
+    Ray r = mkray(ray);
+    int a = -1, b = -1; double d = 1e20;
+    bool f = s->tree->check(s->objs, r, a, b, d);
+    *no = a; *nv = b; *t = d;
+    return f ? 1 : 0;
+}
+
+// sphere_intersect (raytrace.cpp:47)
+int ref_sphere_intersect(void *h, const double *ray, int *id, double *t) {
+    RefScene *s = (RefScene *)h;
+    Ray r = mkray(ray);
+    int i = -1; double d = 1e20;
+    bool f = sphere_intersect(s->spheres.empty() ? NULL : &s->spheres[0], (int)s->spheres.size(), r, i, d);
+    *id = i; *t = d;
+    return f ? 1 : 0;
+}
+
+double ref_sph_intersect(void *h, int i, const double *ray) {
+    RefScene *s = (RefScene *)h;
+    return s->spheres[i].intersect(mkray(ray));
+}
+
+double ref_poly_intersect(void *h, int no, int nv, const double *ray, double *u, double *v) {
+    RefScene *s = (RefScene *)h;
+    double uu = 0, vv = 0;
+    double t = s->objs[no].polys[nv].intersect(mkray(ray), uu, vv);
+    *u = uu; *v = vv;
+    return t;
+}
+
+void ref_poly_getn(void *h, int no, int nv, const double *x, double *out) {
+    RefScene *s = (RefScene *)h;
+    Point3D n = s->objs[no].polys[nv].getn(Point3D(x[0], x[1], x[2]));
+    out[0] = n.x; out[1] = n.y; out[2] = n.z;
+}
+
+void ref_poly_nc(void *h, int no, int nv, double *out) {
+    RefScene *s = (RefScene *)h;
+    const Point3D &n = s->objs[no].polys[nv].nc;
+    out[0] = n.x; out[1] = n.y; out[2] = n.z;
+}
+
+int ref_check_aabb(const double *box /* mi[3], ma[3] */, const double *ray) {
+    KdTreeNode b;
+    for (int k = 0; k < 3; k++) { b.mi[k] = box[k]; b.ma[k] = box[3 + k]; }
+    return b.check_aabb(mkray(ray)) ? 1 : 0;
+}
+
+// Pre-order walk over the reference's tree objects (the order of its own flattening,
+// cuda.cu:68-89). List entries are reported as (no, nv) pairs.
+static int count_nodes(const KdTree *t) { return t ? 1 + count_nodes(t->l) + count_nodes(t->r) : 0; }
+int ref_num_nodes(void *h) { return count_nodes(((RefScene *)h)->tree); }
+
+struct Dump { double *box, *split; int *axis, *left, *right, *first, *count, *list_no, *list_nv; int nn, nl; };
+static int dump(const KdTree *t, Dump &d) {
+    if (!t) return -1;
+    int me = d.nn++;
+    for (int k = 0; k < 3; k++) { d.box[6 * me + k] = t->aabb.mi[k]; d.box[6 * me + 3 + k] = t->aabb.ma[k]; }
+    // leaves never set `split` (kdtree.cpp:36-40); report 0 for them so dumps are comparable
+    d.split[me] = (t->l || t->r || t->node.size() >= 4) ? t->split : 0.0;
+    d.axis[me] = t->w; d.first[me] = d.nl; d.count[me] = (int)t->node.size();
+    for (size_t i = 0; i < t->node.size(); i++) { d.list_no[d.nl] = t->node[i].no; d.list_nv[d.nl] = t->node[i].nv; d.nl++; }
+    int l = dump(t->l, d), r = dump(t->r, d);
+    d.left[me] = l; d.right[me] = r;
+    return me;
+}
+void ref_tree_dump(void *h, double *box, double *split, int *axis, int *left, int *right, int *first, int *count,
+                   int *list_no, int *list_nv) {
+    Dump d = {box, split, axis, left, right, first, count, list_no, list_nv, 0, 0};
+    dump(((RefScene *)h)->tree, d);
+}
+
+// The expression of raytrace.cpp:203, `Ray(cam.o + d * 140, d.norm())`, written with the
+// reference's own Point3D/Ray so that the compiler's argument evaluation order (which decides
+// whether the origin uses d before or after the in-place normalisation) can be observed.
+void ref_primary_ray(const double *camo, const double *dvec, double *out) {
+    Point3D o(camo[0], camo[1], camo[2]), d(dvec[0], dvec[1], dvec[2]);
+    Ray cam(o, Point3D(0, 0, -1));
+    Ray r = Ray(cam.o + d * 140, d.norm());
+    out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z;
+}
+
+// Vector helpers of point.h for known-answer tests.
+void ref_vec_norm(const double *a, double *out) {
+    Point3D p(a[0], a[1], a[2]); p.norm();
+    out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
+} // extern "C"
