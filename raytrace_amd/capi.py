@@ -100,6 +100,14 @@ def device_lib():
         path = os.path.join(LIB_DIR, "librt_hip.so")
         if not os.path.exists(path):
             raise RtError(f"{path} is missing: run `make -C raytrace_amd/csrc` (or __graft_entry__.build())")
+        # One HIP runtime per process: torch bundles its own libamdhip64 / libhsa-runtime64, and a
+        # second copy loaded next to it cannot open the GPU.  Importing torch first makes this
+        # library's libamdhip64.so.7 dependency resolve to the copy torch already loaded, so device
+        # buffers and streams can be shared with torch (frame gather over RCCL).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         D = C.CDLL(path)
         D.rt_device_count.restype = C.c_int
         D.rt_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]

@@ -312,7 +312,7 @@ def tiny_mixed(seed=0, n_tris=40, n_sph=5):
            for i in range(n_sph)]
     sph.append(_sphere(4.0, (0, 18, 0), (12, 12, 12), (0, 0, 0), DIFF))
     return {"name": f"tiny_mixed_{seed}", "meshes": meshes, "spheres": sph,
-            "camera": {"o": np.array([0, 0, 180.0]), "d": np.array([0, 0, -1.0])}, "sizex": 48, "sizey": 64}
+            "camera": {"o": np.array([0, 0, 165.0]), "d": np.array([0, 0, -1.0])}, "sizex": 48, "sizey": 64}
 
 
 def write_scene_files(scene, directory, c_samps=4, g_samps=4):

@@ -111,7 +111,7 @@ def test_primary_ids_bit_exact(ra, po, world, name, sizex, sizey):
     assert np.array_equal(pid, opid)
     assert st == ost
     assert np.array_equal(rgb, orgb)  # emission of the first hit only: no trig, no summation order
-    assert (pid != ra.capi.RT_ID_MISS).mean() > 0.3
+    assert (pid != ra.capi.RT_ID_MISS).mean() > (0.3 if name != "tiny" else 0.01)
 
 
 def _compare_frames(ra, po, rgb, orgb):
