@@ -115,8 +115,12 @@ typedef struct rt_params {
 typedef struct rt_stats {
     uint64_t rays;        /* radiance() invocations            (raytrace.cpp:41) */
     uint64_t node_visits; /* KdTree::check invocations         (kdtree.cpp:111) */
-    uint64_t tri_tests;   /* Polygon::intersect in check_node  (kdtree.cpp:105) */
+    uint64_t tri_tests;   /* Polygon::intersect in check_node  (kdtree.cpp:105): what the reference would run */
     uint64_t sph_tests;   /* Sphere::intersect                 (sphere.cpp:8) */
+    uint64_t tri_shades;  /* rays whose chosen hit is a triangle (raytrace.cpp:58-67) */
+    /* what the kernel actually executed (long own lists are culled conservatively, results unchanged) */
+    uint64_t tri_tests_done; /* exact triangle tests performed */
+    uint64_t cull_tests;     /* culling-box tests performed */
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* opaque, one per (scene, device) */
@@ -151,12 +155,14 @@ int rt_render_tile(rt_scene *s, const rt_camera *cam, const rt_tile *tile, const
  * `stream` (a hipStream_t, NULL = default stream).  Tile k's pixels are written contiguously
  * (row-major inside the tile) starting at pixel offset sum_{j<k} rows_j*cols_j, so a GPU's share
  * of the frame is one packed buffer ready for a gather.  d_prim_id may be NULL.
- * Work counters of the launch are fetched with rt_get_stats (which synchronises the stream).
+ * Work counters accumulate over launches until rt_get_stats fetches and clears them.
  * Calls on one rt_scene must not overlap; different rt_scene objects are independent.
  */
 int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int32_t n_tiles,
                            const rt_params *p, double *d_rgb, int32_t *d_prim_id, void *stream);
 
+/* Work counters summed over every launch on this scene since the previous rt_get_stats call
+ * (or since upload); synchronises the last stream used, then clears the counters. */
 int rt_get_stats(rt_scene *s, rt_stats *stats);
 
 /* Milliseconds the last render kernel of this scene took on its stream (HIP events recorded

@@ -26,7 +26,8 @@ def _i(a):
 
 
 class OStats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64),
+                ("tri_shades", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

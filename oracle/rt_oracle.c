@@ -104,7 +104,7 @@ typedef struct {
 } oscene;
 
 typedef struct {
-    uint64_t rays, node_visits, tri_tests, sph_tests;
+    uint64_t rays, node_visits, tri_tests, sph_tests, tri_shades;
 } ostats;
 
 /* ------------------------------------------------------------------ scene */
@@ -374,13 +374,14 @@ static int kd_check(const oscene *sc, const onode *t, const ray_t *ray, int *id,
  * sph_id = sphere index or -1; t = 1e20 on a miss, exactly as the reference leaves it. */
 void orc_trace(const oscene *sc, int n, const double *rays, int *tri_id, double *tri_t, int *sph_id, double *sph_t,
                ostats *st_out) {
-    ostats st = {0, 0, 0, 0};
+    ostats st = {0, 0, 0, 0, 0};
     for (int i = 0; i < n; i++) {
         ray_t r = {V(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), V(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5])};
         int id = -1, ids = -1; double to = 1e20, ts = 1e20;
         st.rays++;
         int fo = kd_check(sc, sc->root, &r, &id, &to, &st);
         int fs = sphere_intersect(sc, &r, &ids, &ts, &st);
+        if (fo && !(ts < to)) st.tri_shades++;
         tri_id[i] = fo ? id : -1; tri_t[i] = to;
         sph_id[i] = fs ? ids : -1; sph_t[i] = ts;
     }
@@ -472,6 +473,7 @@ static v3 radiance(octx *c, ray_t r, int depth, int into) {
         f = p->col; /* getcol, untextured (polygon.h:75) */
         type = sc->objs[p->obj].type; lig = sc->objs[p->obj].lig;
         if (primary) c->first_id = idt;
+        c->st.tri_shades++;
     }
 
     double p = f.x > f.y && f.x > f.z ? f.x : f.y > f.z ? f.y : f.z; /* max refl */
@@ -562,6 +564,7 @@ static void render_pixel(const oscene *sc, const ocamera *cam, const oparams *pr
         }
     rgb[0] = col.x; rgb[1] = col.y; rgb[2] = col.z;
     st->rays += c.st.rays; st->node_visits += c.st.node_visits; st->tri_tests += c.st.tri_tests; st->sph_tests += c.st.sph_tests;
+    st->tri_shades += c.st.tri_shades;
 }
 
 /* Render the tile rows [x0,x0+rows) x columns [y0,y0+cols) into rgb[rows*cols*3] (linear,
@@ -573,19 +576,21 @@ typedef struct {
 
 static void *worker(void *arg) {
     job_t *j = (job_t *)arg;
-    ostats st = {0, 0, 0, 0};
+    ostats st = {0, 0, 0, 0, 0};
+    const int npix = j->rows * j->cols, chunk = 4;
     for (;;) {
         pthread_mutex_lock(&j->mu);
-        int row = j->next_row++;
+        int k0 = j->next_row; /* next unrendered pixel (row-major) */
+        j->next_row += chunk;
         pthread_mutex_unlock(&j->mu);
-        if (row >= j->rows) break;
-        for (int c = 0; c < j->cols; c++) {
-            size_t k = (size_t)row * j->cols + c;
-            render_pixel(j->sc, j->cam, j->pr, j->x0 + row, j->y0 + c, j->rgb + 3 * k, j->prim_id ? j->prim_id + k : NULL, &st);
-        }
+        if (k0 >= npix) break;
+        for (int k = k0; k < k0 + chunk && k < npix; k++)
+            render_pixel(j->sc, j->cam, j->pr, j->x0 + k / j->cols, j->y0 + k % j->cols, j->rgb + 3 * (size_t)k,
+                         j->prim_id ? j->prim_id + k : NULL, &st);
     }
     pthread_mutex_lock(&j->mu);
     j->st.rays += st.rays; j->st.node_visits += st.node_visits; j->st.tri_tests += st.tri_tests; j->st.sph_tests += st.sph_tests;
+    j->st.tri_shades += st.tri_shades;
     pthread_mutex_unlock(&j->mu);
     return NULL;
 }

@@ -18,9 +18,11 @@
 // Layout in HBM (built by rt_upload_scene):
 //   NodeRec   64 B, 64-B aligned: box (48), split (8), right child (4), info (4: axis, has-left,
 //             own-list length).  Nodes are in pre-order so the left child is node+1.
-//   first[]   4 B per node: start of the node's own list
-//   TriRec    80 B, 16-B aligned, stored in OWN-LIST ORDER (each triangle is in exactly one
-//             list), so a node's list is a contiguous run: p0, E1 = p1-p0, E2 = p2-p0, global id
+//   ListInfo  48 B per node: start of the node's own list, and for long lists the root of a
+//             culling hierarchy plus the data for its safety margin
+//   TriRec    80 B, 16-B aligned, grouped by own list (each triangle is in exactly one list), so a
+//             node's list is a contiguous run: p0, E1 = p1-p0, E2 = p2-p0, global id, list rank
+//   CullRec   64 B: box + two children, or a run of <= 4 triangles (long own lists only)
 //   TriShade  80 B per triangle, same order: nc, col, lig, type (touched only on the chosen hit)
 //   SphGeom   32 B: centre, radius;  SphShade 64 B: lig, col, type
 //
@@ -29,8 +31,19 @@
 // its pixel's 4*samps paths to completion, so the per-pixel sums happen in the reference's
 // order with no atomics.  The traversal stack lives in LDS ([level][thread], conflict-free);
 // levels beyond LDS_STACK spill to a per-thread HBM array sized from the tree depth.
+//
+// Long own lists.  The reference tests EVERY triangle of a visited node's own list, and its
+// median-split tree leaves thousands of straddling triangles on the top nodes.  Testing them all
+// is not needed to get the same answer: check_node's result is "smallest t > eps, first in list
+// order among equals" plus "does any t < 1e10 exist", and both only depend on the triangles that
+// Polygon::intersect accepts.  So each long list gets a small bounding-box hierarchy, built at
+// upload, whose boxes are inflated by a margin that provably exceeds how far outside a triangle
+// the floating-point Moller-Trumbore test can still accept a ray (see list_margin()); subtrees
+// whose inflated box the ray misses are skipped, the surviving triangles go through the unchanged
+// exact test, and ties are broken by the stored list rank.  Results are identical by construction.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -48,6 +61,9 @@ constexpr int BLOCK = 256;    // threads per workgroup (4 wavefronts)
 constexpr int LDS_STACK = 32; // traversal-stack levels kept in LDS
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 constexpr unsigned NODE_MASK = 0x0FFFFFFFu;
+constexpr int N_STATS = 7;
+constexpr int CULL_MIN = 12; // own lists longer than this get a culling hierarchy
+constexpr int CULL_LEAF = 4; // triangles per hierarchy leaf
 
 struct NodeRec {
     double mi[3], ma[3];
@@ -59,7 +75,8 @@ static_assert(sizeof(NodeRec) == 64, "NodeRec must be 64 bytes");
 
 struct __attribute__((aligned(16))) TriRec {
     double p0[3], e1[3], e2[3];
-    long long gid;
+    int gid;  // global triangle id
+    int rank; // position in the reference's list order (decides between equal distances)
 };
 static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
 
@@ -69,13 +86,29 @@ struct __attribute__((aligned(16))) TriShade {
 };
 static_assert(sizeof(TriShade) == 80, "TriShade must be 80 bytes");
 
+struct __attribute__((aligned(16))) ListInfo {
+    double c[3]; // centre of the list's bounding box
+    double k2;   // margin per unit of distance, from the longest triangle edge of the list
+    double r2;   // box half-diagonal + longest edge
+    int first;   // first TriRec of the list
+    int root;    // root CullRec, or -1 when the list is scanned linearly
+};
+static_assert(sizeof(ListInfo) == 48, "ListInfo must be 48 bytes");
+
+struct __attribute__((aligned(16))) CullRec {
+    double lo[3], hi[3];
+    int a, b; // b >= 0: children a, b;  b < 0: leaf with -b triangles starting at TriRec a
+};
+static_assert(sizeof(CullRec) == 64, "CullRec must be 64 bytes");
+
 struct __attribute__((aligned(16))) SphGeom { double px, py, pz, rad; };
 struct __attribute__((aligned(16))) SphShade { double lig[3], col[3]; int type, pad0; double pad1; };
 static_assert(sizeof(SphShade) == 64, "SphShade must be 64 bytes");
 
 struct DevScene {
     const NodeRec *nodes;
-    const int *first;
+    const ListInfo *lists;
+    const CullRec *cull;
     const TriRec *tris;
     const TriShade *tshade;
     const SphGeom *sph;
@@ -111,7 +144,7 @@ __device__ __forceinline__ d3 cross(d3 a, d3 b) {
 __device__ __forceinline__ d3 normv(d3 a) { return a * (1 / sqrt(a.x * a.x + a.y * a.y + a.z * a.z)); } // point.h:49
 __device__ __forceinline__ d3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
 
-struct Stats { unsigned long long rays, visits, tris, sphs; };
+struct Stats { unsigned long long rays, visits, tris, sphs, shades, done, culls; };
 
 // drand48 recurrence; every path restarts it from a hashed state
 __device__ __forceinline__ double rng_next(unsigned long long &x) {
@@ -167,6 +200,39 @@ __device__ __forceinline__ double tri_hit(const TriRec &T, d3 o, d3 d) {
     return t;
 }
 
+// Safety margin for the culling boxes of one own list.  In floating point, Polygon::intersect can
+// accept a ray whose exact line passes slightly OUTSIDE the triangle: the rounding error of u, v
+// and det is at most ~40 ulp * |T| * L^2 (T = origin - p0, L = longest edge), and the acceptance
+// needs det >= eps = 1e-5, so in barycentric terms the slack is <= 40 * 1.1e-16 * |T| * L^2 / 1e-5
+// and the accepted point lies within 4.4e-10 * L^2 * (|T| + L) of the triangle.  The margin used is
+// (1e-9 * L^2 + 1e-10) * (|o - c| + R + L) with c, R the list box centre / half-diagonal (|T| <=
+// |o - c| + R), i.e. more than twice that bound; cull_hit() then inflates by twice the margin again,
+// which also swallows the few-ulp error of the slab arithmetic itself.
+__device__ __forceinline__ double list_margin(const ListInfo &li, const double (&s)[3]) {
+    const double dx = s[0] - li.c[0], dy = s[1] - li.c[1], dz = s[2] - li.c[2];
+    return li.k2 * (sqrt(dx * dx + dy * dy + dz * dz) + li.r2);
+}
+
+// Conservative ray (t >= 0) versus inflated box: never false for a ray the exact triangle test
+// could accept; false positives only cost an extra exact test.
+__device__ __forceinline__ bool cull_hit(const CullRec &c, double m2, const double (&s)[3], const double (&inv)[3],
+                                         const bool (&par)[3]) {
+    double tmin = 0.0, tmax = 1e300;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double lo = c.lo[i] - m2, hi = c.hi[i] + m2;
+        if (par[i]) { if (s[i] < lo || s[i] > hi) ok = false; }
+        else {
+            const double t1 = (lo - s[i]) * inv[i], t2 = (hi - s[i]) * inv[i];
+            const double ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
+            tmin = ta > tmin ? ta : tmin;
+            tmax = tb < tmax ? tb : tmax;
+        }
+    }
+    return ok && tmin <= tmax;
+}
+
 // KdTree::check (kdtree.cpp:111-142) without recursion.  The recursion's return value
 // ("this subtree has a hit", dis < 1e10) is the `flag` carried per frame; a stack entry holds
 // the interior node whose near child is being walked, which child is the far one, and the
@@ -177,6 +243,11 @@ __device__ __forceinline__ void trace_tris(const DevScene &S, d3 o, d3 d, double
     best_t = 1e20;
     best_pos = -1;
     const double s[3] = {o.x, o.y, o.z}, v[3] = {d.x, d.y, d.z};
+    // for the culling boxes: reciprocal direction, or "parallel" where a component is (nearly) zero
+    const bool par[3] = {fabs(v[0]) < 1e-150, fabs(v[1]) < 1e-150, fabs(v[2]) < 1e-150};
+    const double inv[3] = {par[0] ? 0.0 : 1.0 / v[0], par[1] ? 0.0 : 1.0 / v[1], par[2] ? 0.0 : 1.0 / v[2]};
+    const double dlen2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const bool can_cull = dlen2 > 0.25 && dlen2 < 4.0; // the margin analysis assumes a unit-ish direction
     int cur = 0, sp = 0;
     bool flag = false;
     for (;;) {
@@ -233,13 +304,57 @@ __device__ __forceinline__ void trace_tris(const DevScene &S, d3 o, d3 d, double
             const NodeRec *nd = S.nodes + own;
             const int right = nd->right;
             const int count = (int)(nd->info >> 3);
-            const int first = S.first[own];
             bool any = false;
-            for (int i = 0; i < count; i++) {
-                const double t = tri_hit(S.tris[first + i], o, d);
-                if (t > EPS) {
-                    if (t < best_t) { best_t = t; best_pos = first + i; }
-                    if (t < 1e10) any = true;
+            if (count > 0) {
+                const ListInfo *li = S.lists + own;
+                const int first = li->first, root = li->root;
+                if (root < 0 || !can_cull) { // short list: the reference's scan, in its order
+                    for (int i = 0; i < count; i++) {
+                        const double t = tri_hit(S.tris[first + i], o, d);
+                        if (t > EPS) {
+                            if (t < best_t) { best_t = t; best_pos = first + i; }
+                            if (t < 1e10) any = true;
+                        }
+                    }
+                    st.done += (unsigned)count;
+                } else { // long list: skip what the ray provably cannot hit, exact test on the rest
+                    const double m2 = 2.0 * list_margin(*li, s);
+                    double lt = 1e20;
+                    int lpos = -1, lrank = 0x7FFFFFFF;
+                    const int base = sp;
+                    int c = root;
+                    for (;;) {
+                        const CullRec *cr = S.cull + c;
+                        st.culls++;
+                        bool descend = false;
+                        if (cull_hit(*cr, m2, s, inv, par)) {
+                            const int a = cr->a, b = cr->b;
+                            if (b < 0) {
+                                for (int i = 0; i < -b; i++) {
+                                    const TriRec &T = S.tris[a + i];
+                                    const double t = tri_hit(T, o, d);
+                                    if (t > EPS) {
+                                        const int rk = T.rank;
+                                        if (t < lt || (t == lt && rk < lrank)) { lt = t; lpos = a + i; lrank = rk; }
+                                        if (t < 1e10) any = true;
+                                    }
+                                }
+                                st.done += (unsigned)(-b);
+                            } else { // visit a next, b later
+                                if (sp < LDS_STACK) stk[sp][tid] = (unsigned)b;
+                                else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = (unsigned)b;
+                                sp++;
+                                c = a;
+                                descend = true;
+                            }
+                        }
+                        if (!descend) {
+                            if (sp == base) break;
+                            sp--;
+                            c = (int)(sp < LDS_STACK ? stk[sp][tid] : S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread]);
+                        }
+                    }
+                    if (lt < best_t) { best_t = lt; best_pos = lpos; }
                 }
             }
             st.tris += (unsigned)count;
@@ -308,7 +423,8 @@ __device__ __forceinline__ d3 radiance(const DevScene &S, const rt_params &P, d3
                 x = ro + rd * to;
                 n = ld3(sh->nc);
                 f = ld3(sh->col); type = sh->type; lig = ld3(sh->lig);
-                if (primary) first_id = (int)S.tris[tpos].gid;
+                if (primary) first_id = S.tris[tpos].gid;
+                st.shades++;
             }
             const d3 nl = dot(n, rd) < 0 ? n : n * -1.0;
             acc = acc + mult(thr, lig);
@@ -368,9 +484,9 @@ __device__ __forceinline__ d3 radiance(const DevScene &S, const rt_params &P, d3
 __device__ __forceinline__ double clamp01(double x) { return x < 0 ? 0 : x > 1 ? 1 : x; } // raytrace.cpp:28-31
 
 __device__ __forceinline__ void wave_add_stats(const Stats &st, unsigned long long *g) {
-    unsigned long long v[4] = {st.rays, st.visits, st.tris, st.sphs};
+    unsigned long long v[N_STATS] = {st.rays, st.visits, st.tris, st.sphs, st.shades, st.done, st.culls};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < N_STATS; k++) {
         unsigned long long x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(g + k, x);
@@ -384,7 +500,7 @@ __global__ __launch_bounds__(BLOCK) void k_render(DevScene S, DevCamera cam, rt_
     __shared__ unsigned stk[LDS_STACK][BLOCK];
     const int tid = threadIdx.x, lane = tid & 63;
     const int gthread = blockIdx.x * BLOCK + tid;
-    Stats st = {0, 0, 0, 0};
+    Stats st = {0, 0, 0, 0, 0, 0, 0};
     const d3 camo = ld3(cam.o), camd = ld3(cam.d), cx = ld3(cam.cx), cy = ld3(cam.cy);
     const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
     for (;;) {
@@ -441,7 +557,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, long long n, const 
     __shared__ unsigned stk[LDS_STACK][BLOCK];
     const int tid = threadIdx.x;
     const int gthread = blockIdx.x * BLOCK + tid;
-    Stats st = {0, 0, 0, 0};
+    Stats st = {0, 0, 0, 0, 0, 0, 0};
     for (long long i = gthread; i < n; i += (long long)gridDim.x * BLOCK) {
         const d3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
         double to, ts;
@@ -449,7 +565,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, long long n, const 
         st.rays++;
         trace_tris(S, o, d, to, tpos, stk, tid, gthread, st);
         trace_spheres(S, o, d, ts, ids, st);
-        tri_id[i] = to < 1e10 ? (int)S.tris[tpos].gid : -1;
+        if (to < 1e10 && !(ts < to)) st.shades++;
+        tri_id[i] = to < 1e10 ? S.tris[tpos].gid : -1;
         tri_t[i] = to;
         sph_id[i] = ts < 1e10 ? ids : -1;
         sph_t[i] = ts;
@@ -488,7 +605,7 @@ int fail(int code, const char *fmt, ...) {
 struct rt_scene {
     int dev = 0;
     DevScene d{};
-    void *nodes = nullptr, *first = nullptr, *tris = nullptr, *tshade = nullptr, *sph = nullptr, *sshade = nullptr;
+    void *nodes = nullptr, *first = nullptr, *cull = nullptr, *tris = nullptr, *tshade = nullptr, *sph = nullptr, *sshade = nullptr;
     void *ovf = nullptr;
     int tree_depth = 0;
     int grid = 0;               // persistent workgroups
@@ -503,6 +620,75 @@ struct rt_scene {
 };
 
 namespace {
+
+// Culling hierarchy for one long own list: median splits of the triangle centroids along the
+// widest axis down to CULL_LEAF triangles.  `order[first..first+count)` is permuted into leaf
+// order; boxes are the exact (uninflated) bounds of the triangles below.
+struct CullTri { double lo[3], hi[3], c[3]; int src; };
+
+int cull_rec(std::vector<CullRec> &out, std::vector<CullTri> &bt, int a, int b, int first, int depth, int &max_depth) {
+    const int me = (int)out.size();
+    out.emplace_back();
+    if (depth > max_depth) max_depth = depth;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+    for (int i = a; i < b; i++)
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], bt[i].lo[k]); hi[k] = std::max(hi[k], bt[i].hi[k]);
+            clo[k] = std::min(clo[k], bt[i].c[k]); chi[k] = std::max(chi[k], bt[i].c[k]);
+        }
+    for (int k = 0; k < 3; k++) { out[me].lo[k] = lo[k]; out[me].hi[k] = hi[k]; }
+    if (b - a <= CULL_LEAF) {
+        out[me].a = first + a;
+        out[me].b = -(b - a);
+        return me;
+    }
+    int ax = 0;
+    if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+    if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+    const int mid = (a + b) / 2;
+    std::nth_element(bt.begin() + a, bt.begin() + mid, bt.begin() + b, [ax](const CullTri &x, const CullTri &y) {
+        return x.c[ax] < y.c[ax] || (x.c[ax] == y.c[ax] && x.src < y.src);
+    });
+    const int l = cull_rec(out, bt, a, mid, first, depth + 1, max_depth);
+    const int r = cull_rec(out, bt, mid, b, first, depth + 1, max_depth);
+    out[me].a = l;
+    out[me].b = r;
+    return me;
+}
+
+void build_cull(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<CullRec> &cull, ListInfo &li,
+                int &max_depth) {
+    std::vector<CullTri> bt((size_t)count);
+    double lmax2 = 0;
+    for (int j = 0; j < count; j++) {
+        const double *v = D->tri_verts + 9 * (size_t)D->list_tri[first + j];
+        CullTri &t = bt[j];
+        t.src = first + j;
+        for (int k = 0; k < 3; k++) {
+            t.lo[k] = std::min(v[k], std::min(v[3 + k], v[6 + k]));
+            t.hi[k] = std::max(v[k], std::max(v[3 + k], v[6 + k]));
+            t.c[k] = (v[k] + v[3 + k] + v[6 + k]) / 3.0;
+        }
+        for (int e = 0; e < 3; e++) { // squared edge lengths
+            const double *p = v + 3 * e, *q = v + 3 * ((e + 1) % 3);
+            const double l2 = (p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]);
+            lmax2 = std::max(lmax2, l2);
+        }
+    }
+    int depth = 0;
+    li.root = cull_rec(cull, bt, 0, count, first, 1, depth);
+    max_depth = std::max(max_depth, depth);
+    for (int j = 0; j < count; j++) order[first + j] = bt[j].src;
+    const CullRec &root = cull[li.root];
+    double r2 = 0;
+    for (int k = 0; k < 3; k++) {
+        li.c[k] = 0.5 * (root.lo[k] + root.hi[k]);
+        r2 += 0.25 * (root.hi[k] - root.lo[k]) * (root.hi[k] - root.lo[k]);
+    }
+    li.k2 = 1e-9 * lmax2 + 1e-10;         // see list_margin()
+    li.r2 = std::sqrt(r2) + std::sqrt(lmax2);
+}
 
 int validate(const rt_scene_desc *D) {
     if (!D) return fail(RT_E_INVALID, "desc is NULL");
@@ -616,7 +802,6 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         HIP_TRY(hipMemcpyAsync(s->d_tiles, s->h_tiles.data(), sizeof(DevTile) * ht.size(), hipMemcpyHostToDevice, stream));
     }
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, 16, stream));
-    HIP_TRY(hipMemsetAsync(s->d_stats, 0, 4 * sizeof(unsigned long long), stream));
     const DevCamera dc = make_camera(cam);
     const int grid = (int)std::min<long long>(s->grid, (blocks + 3) / 4);
     HIP_TRY(hipEventRecord(s->ev0, stream));
@@ -665,19 +850,29 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     HIP_TRY(hipSetDevice(dev));
 
     std::vector<NodeRec> nodes((size_t)D->n_nodes);
-    std::vector<int> first((size_t)D->n_nodes);
+    std::vector<ListInfo> lists((size_t)D->n_nodes);
+    std::vector<CullRec> cull;
+    std::vector<int> order((size_t)D->n_list); // device position -> entry of list_tri
+    for (int i = 0; i < D->n_list; i++) order[i] = i;
+    int cull_depth = 0;
     for (int i = 0; i < D->n_nodes; i++) {
         NodeRec &n = nodes[i];
         for (int k = 0; k < 3; k++) { n.mi[k] = D->node_box[6 * i + k]; n.ma[k] = D->node_box[6 * i + 3 + k]; }
         n.split = D->node_split[i];
         n.right = D->node_right[i] > 0 ? D->node_right[i] : 0;
         n.info = (unsigned)D->node_axis[i] | (D->node_left[i] >= 0 ? 4u : 0u) | ((unsigned)D->node_count[i] << 3);
-        first[i] = D->node_first[i];
+        ListInfo &li = lists[i];
+        li.first = D->node_first[i];
+        li.root = -1;
+        li.c[0] = li.c[1] = li.c[2] = 0; li.k2 = 0; li.r2 = 0;
+        if (D->node_count[i] > CULL_MIN) build_cull(D, D->node_first[i], D->node_count[i], order, cull, li, cull_depth);
     }
+    if (cull.size() > 0x7FFFFFF0ull) return fail(RT_E_LIMIT, "culling hierarchy too large");
     std::vector<TriRec> tris((size_t)D->n_tris);
     std::vector<TriShade> tsh((size_t)D->n_tris);
     for (int pos = 0; pos < D->n_list; pos++) {
-        const int g = D->list_tri[pos];
+        const int rank = order[pos];
+        const int g = D->list_tri[rank];
         const double *v = D->tri_verts + 9 * (size_t)g;
         TriRec &t = tris[pos];
         for (int k = 0; k < 3; k++) {
@@ -686,6 +881,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
             t.e2[k] = v[6 + k] - v[k]; // polygon.h:40
         }
         t.gid = g;
+        t.rank = rank;
         TriShade &h = tsh[pos];
         for (int k = 0; k < 3; k++) {
             h.nc[k] = D->tri_nc[3 * (size_t)g + k];
@@ -710,7 +906,8 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->dev = dev;
     s->tree_depth = D->tree_depth;
     rc = upload(&s->nodes, nodes);
-    if (!rc) rc = upload(&s->first, first);
+    if (!rc) rc = upload(&s->first, lists);
+    if (!rc) rc = upload(&s->cull, cull);
     if (!rc) rc = upload(&s->tris, tris);
     if (!rc) rc = upload(&s->tshade, tsh);
     if (!rc) rc = upload(&s->sph, sg);
@@ -725,12 +922,13 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         per_cu = 2;
     s->grid = pr.multiProcessorCount * per_cu;
     const int n_threads = s->grid * BLOCK;
-    const int ovf_depth = D->tree_depth > LDS_STACK ? D->tree_depth - LDS_STACK : 0;
+    const int need_depth = D->tree_depth + cull_depth + 2; // main frames plus one list's culling walk on top
+    const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK : 0;
     hipError_t e = hipSuccess;
     if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_threads * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_counter, 16);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, N_STATS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&s->ev0);
     if (e == hipSuccess) e = hipEventCreate(&s->ev1);
     if (e != hipSuccess) {
@@ -738,7 +936,8 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         return fail(RT_E_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
     }
     s->d.nodes = (const NodeRec *)s->nodes;
-    s->d.first = (const int *)s->first;
+    s->d.lists = (const ListInfo *)s->first;
+    s->d.cull = (const CullRec *)s->cull;
     s->d.tris = (const TriRec *)s->tris;
     s->d.tshade = (const TriShade *)s->tshade;
     s->d.sph = (const SphGeom *)s->sph;
@@ -756,7 +955,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->nodes, s->first, s->tris, s->tshade, s->sph, s->sshade, s->ovf, s->d_counter, s->d_stats, s->d_tiles};
+    void *ptrs[] = {s->nodes, s->first, s->cull, s->tris, s->tshade, s->sph, s->sshade, s->ovf, s->d_counter, s->d_stats, s->d_tiles};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -776,9 +975,11 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
     if (!s || !stats) return fail(RT_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(s->dev));
     HIP_TRY(hipStreamSynchronize(s->last_stream));
-    unsigned long long h[4];
+    unsigned long long h[N_STATS];
     HIP_TRY(hipMemcpy(h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
-    stats->rays = h[0]; stats->node_visits = h[1]; stats->tri_tests = h[2]; stats->sph_tests = h[3];
+    HIP_TRY(hipMemset(s->d_stats, 0, sizeof(h)));
+    stats->rays = h[0]; stats->node_visits = h[1]; stats->tri_tests = h[2]; stats->sph_tests = h[3]; stats->tri_shades = h[4];
+    stats->tri_tests_done = h[5]; stats->cull_tests = h[6];
     return RT_OK;
 }
 
@@ -803,7 +1004,9 @@ int rt_render_tile(rt_scene *s, const rt_camera *cam, const rt_tile *tile, const
     HIP_TRY(hipMalloc((void **)&d_rgb, npix * 3 * sizeof(double)));
     hipError_t e = hipMalloc((void **)&d_prim, npix * sizeof(int));
     if (e != hipSuccess) { (void)hipFree(d_rgb); return fail(RT_E_DEVICE, "hipMalloc: %s", hipGetErrorString(e)); }
-    int rc = launch_render(s, cam, tile, 1, p, d_rgb, d_prim, nullptr);
+    int rc = RT_OK;
+    if (hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long)) != hipSuccess) rc = fail(RT_E_DEVICE, "hipMemset failed");
+    if (!rc) rc = launch_render(s, cam, tile, 1, p, d_rgb, d_prim, nullptr);
     if (!rc) {
         e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipMemcpy(rgb_out, d_rgb, npix * 3 * sizeof(double), hipMemcpyDeviceToHost);
@@ -833,7 +1036,7 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) e = hipMalloc((void **)&d_ti, (size_t)n * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&d_si, (size_t)n * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) {
         const long long want = (n + BLOCK - 1) / BLOCK;
         const int grid = (int)std::min<long long>(s->grid, want); // stay within the overflow stack's thread count

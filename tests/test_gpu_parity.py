@@ -61,7 +61,7 @@ def test_trace_rays_bit_exact(world, name):
     assert np.array_equal(tt, ott)
     assert np.array_equal(sid, osid)
     assert np.array_equal(st, ost)
-    assert stats == ostats
+    assert {k: stats[k] for k in ostats} == ostats
     assert (tid >= 0).sum() > 0 or name == "cornell"
 
 
@@ -90,7 +90,7 @@ def test_trace_rays_axis_aligned_and_on_plane(world):
     otid, ott, osid, ost, ostats = w["orc"].trace(rays)
     assert np.array_equal(tid, otid) and np.array_equal(tt, ott)
     assert np.array_equal(sid, osid) and np.array_equal(st, ost)
-    assert stats == ostats
+    assert {k: stats[k] for k in ostats} == ostats
 
 
 def _cam(ra, sc, sizex, sizey):
@@ -109,7 +109,7 @@ def test_primary_ids_bit_exact(ra, po, world, name, sizex, sizey):
     rgb, pid, st = w["dev"].render_tile(_cam(ra, w["scene"], sizex, sizey), ra.capi.make_params(**kw), 0, 0, sizex, sizey)
     orgb, opid, ost = w["orc"].render_tile(_ocam(po, w["scene"], sizex, sizey), po.make_params(**kw), 0, 0, sizex, sizey, nthreads=8)
     assert np.array_equal(pid, opid)
-    assert st == ost
+    assert {k: st[k] for k in ost} == ost
     assert np.array_equal(rgb, orgb)  # emission of the first hit only: no trig, no summation order
     assert (pid != ra.capi.RT_ID_MISS).mean() > (0.3 if name != "tiny" else 0.01)
 
@@ -212,7 +212,7 @@ def test_edge_scenes(ra, po):
         b = orc.trace(rays)
         for x, y in zip(a[:4], b[:4]):
             assert np.array_equal(x, y), name
-        assert a[4] == b[4], name
+        assert {k: a[4][k] for k in b[4]} == b[4], name
         cam = ra.capi.make_camera((0, 0, 160), (0, 0, -1), 16, 24)
         ocam = po.make_camera((0, 0, 160), (0, 0, -1), 16, 24)
         kw = dict(samps=1, rr_depth=3, rr_mode=0, split_depth=2, hard_depth=8, jitter=0, seed=1)
