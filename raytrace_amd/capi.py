@@ -98,7 +98,7 @@ def device_lib():
     """The HIP library. Raises if it is missing -- there is no other implementation to fall back to."""
     global _dev
     if _dev is None:
-        path = os.path.join(LIB_DIR, "librt_hip.so")
+        path = os.environ.get("RT_HIP_LIB") or os.path.join(LIB_DIR, "librt_hip.so")  # RT_HIP_LIB: A/B builds
         if not os.path.exists(path):
             raise RtError(f"{path} is missing: run `make -C raytrace_amd/csrc` (or __graft_entry__.build())")
         # One HIP runtime per process: torch bundles its own libamdhip64 / libhsa-runtime64, and a

@@ -56,22 +56,47 @@
 
 namespace {
 
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 3 // wavefronts per SIMD the register allocation is bounded for
+#endif
+
 constexpr double EPS = 1e-5;  // point.h:7
 constexpr int BLOCK = 256;    // threads per workgroup (4 wavefronts)
-constexpr int LDS_STACK = 32; // traversal-stack levels kept in LDS
+constexpr int LDS_STACK = 24; // traversal-stack levels kept in LDS
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 constexpr unsigned NODE_MASK = 0x0FFFFFFFu;
 constexpr int N_STATS = 7;
 constexpr int CULL_MIN = 12; // own lists longer than this get a culling hierarchy
 constexpr int CULL_LEAF = 4; // triangles per hierarchy leaf
 
-struct NodeRec {
+// All three kinds of traversal record are 64 bytes with their two integer words last, so a lane
+// fetches "its current record" with one instruction sequence whatever the kind.
+struct __attribute__((aligned(16))) NodeRec { // one kd-tree node (KdTree, kdtree.h:96-116)
     double mi[3], ma[3];
     double split;
     int right;     // 0 = none (the root is never a child)
-    unsigned info; // bits 0-1 axis, bit 2 has-left, bits 3.. own-list length
+    unsigned info; // bits 0-1 axis, bit 2 has-left
 };
 static_assert(sizeof(NodeRec) == 64, "NodeRec must be 64 bytes");
+
+struct __attribute__((aligned(16))) CullRec { // one node of a long own list's culling hierarchy
+    double lo[3], hi[3];
+    double pad;
+    int a, b; // b >= 0: children a, b;  b < 0: leaf with -b triangles starting at TriRec a
+};
+static_assert(sizeof(CullRec) == 64, "CullRec must be 64 bytes");
+
+struct __attribute__((aligned(16))) ListRec { // a node's own list (KdTree::node)
+    double c[3]; // centre of the list's bounding box
+    double k2;   // margin per unit of distance, from the longest triangle edge of the list
+    double r2;   // box half-diagonal + longest edge
+    int first;   // first TriRec of the list
+    int root;    // root CullRec, or -1 when the list is scanned linearly
+    int right;   // the node's right child (0 = none), repeated here for the far-child step
+    int count;   // own-list length
+    double pad;
+};
+static_assert(sizeof(ListRec) == 64, "ListRec must be 64 bytes");
 
 struct __attribute__((aligned(16))) TriRec {
     double p0[3], e1[3], e2[3];
@@ -86,34 +111,20 @@ struct __attribute__((aligned(16))) TriShade {
 };
 static_assert(sizeof(TriShade) == 80, "TriShade must be 80 bytes");
 
-struct __attribute__((aligned(16))) ListInfo {
-    double c[3]; // centre of the list's bounding box
-    double k2;   // margin per unit of distance, from the longest triangle edge of the list
-    double r2;   // box half-diagonal + longest edge
-    int first;   // first TriRec of the list
-    int root;    // root CullRec, or -1 when the list is scanned linearly
-};
-static_assert(sizeof(ListInfo) == 48, "ListInfo must be 48 bytes");
-
-struct __attribute__((aligned(16))) CullRec {
-    double lo[3], hi[3];
-    int a, b; // b >= 0: children a, b;  b < 0: leaf with -b triangles starting at TriRec a
-};
-static_assert(sizeof(CullRec) == 64, "CullRec must be 64 bytes");
-
 struct __attribute__((aligned(16))) SphGeom { double px, py, pz, rad; };
 struct __attribute__((aligned(16))) SphShade { double lig[3], col[3]; int type, pad0; double pad1; };
 static_assert(sizeof(SphShade) == 64, "SphShade must be 64 bytes");
 
 struct DevScene {
     const NodeRec *nodes;
-    const ListInfo *lists;
+    const ListRec *lists;
     const CullRec *cull;
     const TriRec *tris;
     const TriShade *tshade;
     const SphGeom *sph;
     const SphShade *sshade;
-    unsigned *ovf;      // overflow stack [ovf_depth][n_threads]
+    unsigned *ovf; // overflow stack [ovf_depth][n_threads]
+    double *lstate; // per-lane path state that is only touched between rays [LS_SLOTS][n_threads]
     int n_nodes, n_tris, n_sph;
     int ovf_depth;
     int n_threads;
@@ -143,8 +154,6 @@ __device__ __forceinline__ d3 cross(d3 a, d3 b) {
 }
 __device__ __forceinline__ d3 normv(d3 a) { return a * (1 / sqrt(a.x * a.x + a.y * a.y + a.z * a.z)); } // point.h:49
 __device__ __forceinline__ d3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
-
-struct Stats { unsigned long long rays, visits, tris, sphs, shades, done, culls; };
 
 // drand48 recurrence; every path restarts it from a hashed state
 __device__ __forceinline__ double rng_next(unsigned long long &x) {
@@ -206,23 +215,24 @@ __device__ __forceinline__ double tri_hit(const TriRec &T, d3 o, d3 d) {
 // needs det >= eps = 1e-5, so in barycentric terms the slack is <= 40 * 1.1e-16 * |T| * L^2 / 1e-5
 // and the accepted point lies within 4.4e-10 * L^2 * (|T| + L) of the triangle.  The margin used is
 // (1e-9 * L^2 + 1e-10) * (|o - c| + R + L) with c, R the list box centre / half-diagonal (|T| <=
-// |o - c| + R), i.e. more than twice that bound; cull_hit() then inflates by twice the margin again,
-// which also swallows the few-ulp error of the slab arithmetic itself.
-__device__ __forceinline__ double list_margin(const ListInfo &li, const double (&s)[3]) {
-    const double dx = s[0] - li.c[0], dy = s[1] - li.c[1], dz = s[2] - li.c[2];
-    return li.k2 * (sqrt(dx * dx + dy * dy + dz * dz) + li.r2);
+// |o - c| + R), i.e. more than twice that bound; the boxes are then inflated by twice the margin
+// again, which also swallows the few-ulp error of the slab arithmetic itself.  The analysis
+// assumes a direction of roughly unit length; other rays take the full scan.
+__device__ __forceinline__ double list_margin(double cx, double cy, double cz, double k2, double r2, const double (&s)[3]) {
+    const double dx = s[0] - cx, dy = s[1] - cy, dz = s[2] - cz;
+    return k2 * (sqrt(dx * dx + dy * dy + dz * dz) + r2);
 }
 
 // Conservative ray (t >= 0) versus inflated box: never false for a ray the exact triangle test
-// could accept; false positives only cost an extra exact test.
-__device__ __forceinline__ bool cull_hit(const CullRec &c, double m2, const double (&s)[3], const double (&inv)[3],
-                                         const bool (&par)[3]) {
+// could accept; a false positive only costs an extra exact test.
+__device__ __forceinline__ bool cull_hit(const double (&lo0)[3], const double (&hi0)[3], double m2, const double (&s)[3],
+                                         const double (&inv)[3], unsigned par) {
     double tmin = 0.0, tmax = 1e300;
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const double lo = c.lo[i] - m2, hi = c.hi[i] + m2;
-        if (par[i]) { if (s[i] < lo || s[i] > hi) ok = false; }
+        const double lo = lo0[i] - m2, hi = hi0[i] + m2;
+        if ((par >> i) & 1) { if (s[i] < lo || s[i] > hi) ok = false; }
         else {
             const double t1 = (lo - s[i]) * inv[i], t2 = (hi - s[i]) * inv[i];
             const double ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
@@ -233,140 +243,8 @@ __device__ __forceinline__ bool cull_hit(const CullRec &c, double m2, const doub
     return ok && tmin <= tmax;
 }
 
-// KdTree::check (kdtree.cpp:111-142) without recursion.  The recursion's return value
-// ("this subtree has a hit", dis < 1e10) is the `flag` carried per frame; a stack entry holds
-// the interior node whose near child is being walked, which child is the far one, and the
-// frame's flag at the time of the descent.  Order per node: near child, own list, far child;
-// strict < keeps the first of equal distances, as the nested comparisons of the reference do.
-__device__ __forceinline__ void trace_tris(const DevScene &S, d3 o, d3 d, double &best_t, int &best_pos,
-                                           unsigned (*stk)[BLOCK], int tid, int gthread, Stats &st) {
-    best_t = 1e20;
-    best_pos = -1;
-    const double s[3] = {o.x, o.y, o.z}, v[3] = {d.x, d.y, d.z};
-    // for the culling boxes: reciprocal direction, or "parallel" where a component is (nearly) zero
-    const bool par[3] = {fabs(v[0]) < 1e-150, fabs(v[1]) < 1e-150, fabs(v[2]) < 1e-150};
-    const double inv[3] = {par[0] ? 0.0 : 1.0 / v[0], par[1] ? 0.0 : 1.0 / v[1], par[2] ? 0.0 : 1.0 / v[2]};
-    const double dlen2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-    const bool can_cull = dlen2 > 0.25 && dlen2 < 4.0; // the margin analysis assumes a unit-ish direction
-    int cur = 0, sp = 0;
-    bool flag = false;
-    for (;;) {
-        int own = -1, farkind = 0;
-        bool near_hit = false;
-        if (cur >= 0) { // enter node `cur`
-            const NodeRec *nd = S.nodes + cur;
-            const double mi[3] = {nd->mi[0], nd->mi[1], nd->mi[2]}, ma[3] = {nd->ma[0], nd->ma[1], nd->ma[2]};
-            const double split = nd->split;
-            const int right = nd->right;
-            const unsigned info = nd->info;
-            st.visits++;
-            if (!aabb_hit(mi, ma, s, v)) cur = -1;
-            else {
-                const int axis = info & 3;
-                const bool hasL = (info >> 2) & 1, hasR = right > 0;
-                const double sw = axis == 0 ? s[0] : axis == 1 ? s[1] : s[2];
-                const double vw = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
-                int near = -1;
-                if (!hasL && !hasR) { /* leaf, or interior node whose triangles all straddle */ }
-                else if (sw < split) { // kdtree.cpp:119-127
-                    if (hasL) near = cur + 1;
-                    if (hasR && vw > 0) farkind = 2;
-                } else if (sw > split) { // kdtree.cpp:128-136
-                    if (hasR) near = right;
-                    if (hasL && vw < 0) farkind = 1;
-                } else { // kdtree.cpp:137-141: on the plane, only the child the ray points into
-                    if (vw < 0 && hasL) near = cur + 1;
-                    else if (vw > 0 && hasR) near = right;
-                }
-                if (near >= 0) {
-                    const unsigned e = (unsigned)cur | ((unsigned)farkind << 28) | ((unsigned)flag << 30);
-                    if (sp < LDS_STACK) stk[sp][tid] = e;
-                    else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = e;
-                    sp++;
-                    flag = false;
-                    cur = near;
-                } else {
-                    own = cur;
-                    cur = -1;
-                }
-            }
-        }
-        if (cur < 0 && own < 0) { // a subtree has returned
-            if (sp == 0) break;
-            sp--;
-            const unsigned e = sp < LDS_STACK ? stk[sp][tid] : S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread];
-            own = (int)(e & NODE_MASK);
-            farkind = (e >> 28) & 3;
-            near_hit = flag;
-            flag = ((e >> 30) & 1) | near_hit;
-        }
-        if (own >= 0) { // check_node (kdtree.cpp:98-109), then the far child
-            const NodeRec *nd = S.nodes + own;
-            const int right = nd->right;
-            const int count = (int)(nd->info >> 3);
-            bool any = false;
-            if (count > 0) {
-                const ListInfo *li = S.lists + own;
-                const int first = li->first, root = li->root;
-                if (root < 0 || !can_cull) { // short list: the reference's scan, in its order
-                    for (int i = 0; i < count; i++) {
-                        const double t = tri_hit(S.tris[first + i], o, d);
-                        if (t > EPS) {
-                            if (t < best_t) { best_t = t; best_pos = first + i; }
-                            if (t < 1e10) any = true;
-                        }
-                    }
-                    st.done += (unsigned)count;
-                } else { // long list: skip what the ray provably cannot hit, exact test on the rest
-                    const double m2 = 2.0 * list_margin(*li, s);
-                    double lt = 1e20;
-                    int lpos = -1, lrank = 0x7FFFFFFF;
-                    const int base = sp;
-                    int c = root;
-                    for (;;) {
-                        const CullRec *cr = S.cull + c;
-                        st.culls++;
-                        bool descend = false;
-                        if (cull_hit(*cr, m2, s, inv, par)) {
-                            const int a = cr->a, b = cr->b;
-                            if (b < 0) {
-                                for (int i = 0; i < -b; i++) {
-                                    const TriRec &T = S.tris[a + i];
-                                    const double t = tri_hit(T, o, d);
-                                    if (t > EPS) {
-                                        const int rk = T.rank;
-                                        if (t < lt || (t == lt && rk < lrank)) { lt = t; lpos = a + i; lrank = rk; }
-                                        if (t < 1e10) any = true;
-                                    }
-                                }
-                                st.done += (unsigned)(-b);
-                            } else { // visit a next, b later
-                                if (sp < LDS_STACK) stk[sp][tid] = (unsigned)b;
-                                else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = (unsigned)b;
-                                sp++;
-                                c = a;
-                                descend = true;
-                            }
-                        }
-                        if (!descend) {
-                            if (sp == base) break;
-                            sp--;
-                            c = (int)(sp < LDS_STACK ? stk[sp][tid] : S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread]);
-                        }
-                    }
-                    if (lt < best_t) { best_t = lt; best_pos = lpos; }
-                }
-            }
-            st.tris += (unsigned)count;
-            flag = flag | any;
-            if (farkind != 0 && !near_hit) cur = farkind == 1 ? own + 1 : right;
-            else cur = -1;
-        }
-    }
-}
-
 // sphere.cpp:3-14 over sphere.h:13-21: scan from the last sphere down, strict <
-__device__ __forceinline__ void trace_spheres(const DevScene &S, d3 o, d3 d, double &ts, int &ids, Stats &st) {
+__device__ __forceinline__ void trace_spheres(const DevScene &S, d3 o, d3 d, double &ts, int &ids) {
     ts = 1e20;
     ids = -1;
     for (int i = S.n_sph; i--;) {
@@ -383,195 +261,421 @@ __device__ __forceinline__ void trace_spheres(const DevScene &S, d3 o, d3 d, dou
         }
         if (t < ts) { ts = t; ids = i; }
     }
-    st.sphs += (unsigned)S.n_sph;
 }
 
 struct Pending { d3 o, d, thr; int depth; int into; };
 
-// radiance() (raytrace.cpp:41-95) as a loop.  Emission is summed front to back with the path
-// throughput `thr`; where the reference traces both glass branches (depth <= split_depth) the
-// reflection branch is parked and the refraction branch is followed first, which is the order
-// the random stream is consumed in.
-__device__ __forceinline__ d3 radiance(const DevScene &S, const rt_params &P, d3 ro, d3 rd, unsigned long long &rng,
-                                       unsigned (*stk)[BLOCK], int tid, int gthread, Stats &st, int &first_id) {
-    d3 acc = mk(0, 0, 0), thr = mk(1, 1, 1);
-    int depth = 0;
-    bool into = true;
-    Pending pend[MAX_SPLIT];
-    int np = 0;
-    bool primary = true;
-    for (;;) {
-        double to, ts;
-        int tpos, ids;
-        st.rays++;
-        trace_tris(S, ro, rd, to, tpos, stk, tid, gthread, st);
-        trace_spheres(S, ro, rd, ts, ids, st);
-        const bool fo = to < 1e10, fs = ts < 1e10;
-        bool go_on = false;
-        if (fo || fs) {
-            d3 x, n, f, lig;
-            int type;
-            if (ts < to || !fo) { // raytrace.cpp:52-57
-                const SphGeom g = S.sph[ids];
-                const SphShade sh = S.sshade[ids];
-                x = ro + rd * ts;
-                n = normv(x - mk(g.px, g.py, g.pz));
-                f = ld3(sh.col); type = sh.type; lig = ld3(sh.lig);
-                if (primary) first_id = -1 - ids;
-            } else { // raytrace.cpp:58-67; getn() returns the face normal (polygon.h:67-69)
-                const TriShade *sh = S.tshade + tpos;
-                x = ro + rd * to;
-                n = ld3(sh->nc);
-                f = ld3(sh->col); type = sh->type; lig = ld3(sh->lig);
-                if (primary) first_id = S.tris[tpos].gid;
-                st.shades++;
-            }
-            const d3 nl = dot(n, rd) < 0 ? n : n * -1.0;
-            acc = acc + mult(thr, lig);
-            const double p = f.x > f.y && f.x > f.z ? f.x : f.y > f.z ? f.y : f.z; // raytrace.cpp:69
-            ++depth;
-            go_on = true;
-            if (depth > P.hard_depth) go_on = false;
-            else if (depth > P.rr_depth) { // raytrace.cpp:70-74
-                if (P.rr_mode && rng_next(rng) < p) f = f * (1 / p);
-                else go_on = false;
-            }
-            if (go_on) {
-                thr = mult(thr, f);
-                if (type == RT_DIFF) { // raytrace.cpp:77-82
-                    const double r1 = 2 * M_PI * rng_next(rng), r2 = rng_next(rng), r2s = sqrt(r2);
-                    const d3 w = nl, u = normv(cross(fabs(w.x) > .1 ? mk(0, 1, 0) : mk(1, 0, 0), w)), vv = cross(w, u);
-                    const d3 nd = normv(u * cos(r1) * r2s + vv * sin(r1) * r2s + w * sqrt(1 - r2));
-                    ro = x - rd * EPS;
-                    rd = nd;
-                } else if (type == RT_SPEC) { // raytrace.cpp:83-84
-                    const d3 nd = rd - n * 2.0 * dot(n, rd);
-                    ro = x - rd * EPS;
-                    rd = nd;
-                } else { // raytrace.cpp:86-94
-                    const d3 reflo = x - rd * EPS, refld = rd - n * 2.0 * dot(n, rd);
-                    const double nc = 1, nt = 1.7, nnt = into ? nc / nt : nt / nc, ddn = dot(rd, nl);
-                    const double cos2t = 1 - nnt * nnt * (1 - ddn * ddn);
-                    if (cos2t < 0) { ro = reflo; rd = refld; } // total internal reflection
-                    else {
-                        const d3 tdir = normv(rd * nnt - n * ((into ? 1 : -1) * (ddn * nnt + sqrt(cos2t))));
-                        const double a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(tdir, n));
-                        const double Re = R0 + (1 - R0) * c * c * c * c * c, Tr = 1 - Re, Pp = .25 + .5 * Re, RP = Re / Pp,
-                                     TP = Tr / (1 - Pp);
-                        const d3 refro = x + rd * EPS;
-                        if (depth > P.split_depth) {
-                            if (rng_next(rng) < Pp) { thr = thr * RP; ro = reflo; rd = refld; }
-                            else { thr = thr * TP; ro = refro; rd = tdir; into = !into; }
-                        } else {
-                            Pending &q = pend[np++];
-                            q.o = reflo; q.d = refld; q.thr = thr * Re; q.depth = depth; q.into = into;
-                            thr = thr * Tr; ro = refro; rd = tdir; into = !into;
-                        }
-                    }
-                }
-            }
-        } else if (primary) first_id = RT_ID_MISS;
-        primary = false;
-        if (!go_on) { // this branch of the path is finished: resume a parked branch or stop
-            if (np == 0) break;
-            const Pending &q = pend[--np];
-            ro = q.o; rd = q.d; thr = q.thr; depth = q.depth; into = q.into != 0;
-        }
-    }
-    return acc;
-}
-
 __device__ __forceinline__ double clamp01(double x) { return x < 0 ? 0 : x > 1 ? 1 : x; } // raytrace.cpp:28-31
 
-__device__ __forceinline__ void wave_add_stats(const Stats &st, unsigned long long *g) {
-    unsigned long long v[N_STATS] = {st.rays, st.visits, st.tris, st.sphs, st.shades, st.done, st.culls};
-#pragma unroll
-    for (int k = 0; k < N_STATS; k++) {
-        unsigned long long x = v[k];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if ((threadIdx.x & 63) == 0 && x) atomicAdd(g + k, x);
-    }
+// sin and cos of x in [0, 2*pi) (the only argument range radiance() needs, raytrace.cpp:79-81):
+// quadrant reduction with a two-part pi/2 and the classic minimax kernels on [-pi/4, pi/4];
+// within 1.2e-16 of libm over the whole range, with a fraction of the registers of the general
+// routine.
+__device__ __forceinline__ void sincos_2pi(double x, double &sn, double &cs) {
+    const int k = (int)(x * 0.63661977236758134308 + 0.5);
+    const double y = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    const double z = y * y;
+    const double rs = 8.33333333332248946124e-03 +
+                      z * (-1.98412698298579493134e-04 +
+                           z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double ks = y + (z * y) * (-1.66666666666666324348e-01 + z * rs);
+    const double rc = z * (4.16666666666666019037e-02 +
+                           z * (-1.38888888888741095749e-03 +
+                                z * (2.48015872894767294178e-05 +
+                                     z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double kc = 1.0 - (0.5 * z - z * rc);
+    const int q = k & 3;
+    sn = q == 0 ? ks : q == 1 ? kc : q == 2 ? -ks : -kc;
+    cs = q == 0 ? kc : q == 1 ? -ks : q == 2 ? -kc : ks;
 }
 
-// One wavefront = one 8x8 pixel block at a time, pulled from `counter`; one pixel per lane.
-__global__ __launch_bounds__(BLOCK) void k_render(DevScene S, DevCamera cam, rt_params P, const DevTile *tiles, int n_tiles,
-                                                  unsigned n_blocks, unsigned *counter, double *rgb, int *prim,
-                                                  unsigned long long *gstats) {
+// A traversal work item, 32 bits; the per-lane stack holds these.
+//   node item   : node index                                   (enter the node: KdTree::check)
+//   cull item   : IT_CULL | CullRec index                      (one box of a long own list)
+//   after item  : IT_AFTER | flag << 30 | far << 28 | node     (the node's near child is done: own
+//                 list, then the far child; `flag` is the enclosing frame's "has a hit" so far)
+constexpr unsigned IT_CULL = 1u << 30, IT_AFTER = 1u << 31, CULL_MASK = 0x3FFFFFFFu;
+enum { PH_STEP = 0, PH_TRIS = 1, PH_SHADE = 2, PH_DONE = 3 };
+enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS };
+// slots of the per-lane state kept in HBM (one double each, [slot][thread] so lanes coalesce)
+enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_SLOTS = 12 };
+
+// The whole path -- camera ray, KdTree::check without recursion, check_node, sphere scan, radiance()
+// as a loop -- runs as ONE loop per wavefront in which every lane is a small state machine, and in
+// every iteration the wavefront executes the one kind of work that most of its lanes are waiting
+// for:
+//     node   enter a kd-tree node: check_aabb, choose near / far child          (kdtree.cpp:111-141)
+//     after  a node's near child is finished: start its own list, queue the far child
+//     cull   one box of a long own list's culling hierarchy
+//     tris   a run of <= CULL_MIN exact triangle tests                          (kdtree.cpp:98-109)
+//     shade  sphere scan, material, next ray / next path / next pixel           (raytrace.cpp:41-95,196-205)
+// Lanes that are waiting for another kind simply sit out the iteration, so they pile up until
+// their kind wins the vote; each executed instruction therefore has many active lanes although
+// the 64 rays of a packet diverge completely after the first bounce.  A lane fetches the 64-byte
+// record of its next item as soon as the item is known, so the load is usually complete by the
+// time the lane's kind is scheduled.
+//
+// TRACE = false: lanes pull pixels (8x8 blocks, one lane per pixel) from an atomic counter and
+// run each pixel's 4*samps paths in the reference's order.  TRACE = true: lanes pull explicit rays
+// and report the nearest triangle / sphere (raytrace.cpp:46-47).
+template <bool TRACE>
+__global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCamera cam, rt_params P, const DevTile *tiles, int n_tiles,
+                                                unsigned n_work, unsigned *counter, double *rgb, int *prim, const double *rays,
+                                                int *tri_id, double *tri_t, int *sph_id, double *sph_t,
+                                                unsigned long long *gstats) {
     __shared__ unsigned stk[LDS_STACK][BLOCK];
+    __shared__ unsigned long long sacc[N_STATS][BLOCK];
     const int tid = threadIdx.x, lane = tid & 63;
     const int gthread = blockIdx.x * BLOCK + tid;
-    Stats st = {0, 0, 0, 0, 0, 0, 0};
-    const d3 camo = ld3(cam.o), camd = ld3(cam.d), cx = ld3(cam.cx), cy = ld3(cam.cy);
-    const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
-    for (;;) {
-        unsigned blk = 0;
-        if (lane == 0) blk = atomicAdd(counter, 1u);
-        blk = __shfl(blk, 0, 64);
-        if (blk >= n_blocks) break;
-        int lo = 0, hi = n_tiles - 1; // last tile whose first block is <= blk
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if ((unsigned)tiles[mid].blk_first <= blk) lo = mid; else hi = mid - 1;
-        }
-        const DevTile T = tiles[lo];
-        const int b = (int)blk - T.blk_first;
-        const int lrow = (b / T.blk_cols) * 8 + (lane >> 3), lcol = (b % T.blk_cols) * 8 + (lane & 7);
-        if (lrow < T.rows && lcol < T.cols) {
-            const int x = T.x0 + lrow, y = T.y0 + lcol;
-            d3 col = mk(0, 0, 0);
-            int first_id = RT_ID_MISS, pix_id = RT_ID_MISS;
-            for (int sx = 0; sx < 2; sx++)
-                for (int sy = 0; sy < 2; sy++) { // raytrace.cpp:196-206
-                    d3 r = mk(0, 0, 0);
-                    for (int s = 0; s < samps; s++) {
-                        const unsigned long long path =
-                            ((((unsigned long long)x * (unsigned long long)sizey + (unsigned long long)y) * 2 + sx) * 2 + sy) *
-                                (unsigned long long)samps + s;
-                        unsigned long long rng = path_state(P.seed, path);
-                        double dx = 0, dy = 0;
-                        if (P.jitter) {
-                            const double r1 = 2 * rng_next(rng); dx = r1 < 1 ? sqrt(r1) - 1 : 1 - sqrt(2 - r1);
-                            const double r2 = 2 * rng_next(rng); dy = r2 < 1 ? sqrt(r2) - 1 : 1 - sqrt(2 - r2);
-                        }
-                        const d3 dd = cx * (((sx + .5 + dx) / 2 + x) / sizex - .5) + cy * (((sy + .5 + dy) / 2 + y) / sizey - .5) + camd;
-                        // raytrace.cpp:203: d is normalised in place before the origin is formed
-                        // (g++ evaluates the constructor arguments right to left)
-                        const d3 dn = normv(dd);
-                        const d3 L = radiance(S, P, camo + dn * 140.0, dn, rng, stk, tid, gthread, st, first_id);
-                        if (sx == 0 && sy == 0 && s == 0) pix_id = first_id;
-                        r = r + L * (1.0 / samps);
-                    }
-                    col = col + mk(clamp01(r.x), clamp01(r.y), clamp01(r.z)) * .25;
-                }
-            const size_t k = (size_t)T.out_off + (size_t)lrow * T.cols + lcol;
-            rgb[3 * k] = col.x; rgb[3 * k + 1] = col.y; rgb[3 * k + 2] = col.z;
-            if (prim) prim[k] = pix_id;
-        }
-    }
-    wave_add_stats(st, gstats);
-}
+    const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int k = 0; k < N_STATS; k++) sacc[k][tid] = 0;
+    // work counters live in LDS (one add per event, no registers held across the loop)
+    auto count = [&](int k, unsigned n) __attribute__((always_inline)) {
+        __hip_atomic_fetch_add(&sacc[k][tid], (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    double *const ls = S.lstate + gthread;
+    const size_t lss = (size_t)S.n_threads;
+    auto ls_get3 = [&](int slot) __attribute__((always_inline)) { return mk(ls[slot * lss], ls[(slot + 1) * lss], ls[(slot + 2) * lss]); };
+    auto ls_put3 = [&](int slot, d3 a) __attribute__((always_inline)) { ls[slot * lss] = a.x; ls[(slot + 1) * lss] = a.y; ls[(slot + 2) * lss] = a.z; };
 
-// raytrace.cpp:46-47 for explicit rays, one ray per lane
-__global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, long long n, const double *rays, int *tri_id, double *tri_t,
-                                                 int *sph_id, double *sph_t, unsigned long long *gstats) {
-    __shared__ unsigned stk[LDS_STACK][BLOCK];
-    const int tid = threadIdx.x;
-    const int gthread = blockIdx.x * BLOCK + tid;
-    Stats st = {0, 0, 0, 0, 0, 0, 0};
-    for (long long i = gthread; i < n; i += (long long)gridDim.x * BLOCK) {
-        const d3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
-        double to, ts;
-        int tpos, ids;
-        st.rays++;
-        trace_tris(S, o, d, to, tpos, stk, tid, gthread, st);
-        trace_spheres(S, o, d, ts, ids, st);
-        if (to < 1e10 && !(ts < to)) st.shades++;
-        tri_id[i] = to < 1e10 ? S.tris[tpos].gid : -1;
-        tri_t[i] = to;
-        sph_id[i] = ts < 1e10 ? ids : -1;
-        sph_t[i] = ts;
+    // ---- per-lane state
+    int phase = PH_SHADE;
+    bool have_hit = false;          // a finished traversal is waiting to be shaded
+    // ray
+    double s[3] = {0, 0, 0}, v[3] = {0, 0, 1}, inv[3] = {0, 0, 0};
+    unsigned par = 0;
+    bool can_cull = false;
+    // traversal
+    unsigned cur = 0;
+    double rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int sp = 0;
+    bool flag = false;
+    double best_t = 1e20, m2 = 0;
+    int best_pos = -1, best_rank = 0, list_first = 0, list_end = 0, tb_first = 0, tb_n = 0;
+    // path / pixel (render mode); throughput, radiance sums and colour sums live in S.lstate
+    unsigned long long rng = 0;
+    int depth = 0, np = 0, sub = 0, smp = 0;
+    unsigned pxy = 0;  // pixel row << 16 | column
+    bool into = true, primary = true;
+    unsigned outk = 0; // render: index of the pixel in the packed output; trace: index of the ray
+    Pending pend[MAX_SPLIT];
+
+    const d3 camo = ld3(cam.o), camd = ld3(cam.d), ccx = ld3(cam.cx), ccy = ld3(cam.cy);
+    const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
+
+    auto load_rec = [&](unsigned item) __attribute__((always_inline)) {
+        const char *base = (item & IT_AFTER) ? (const char *)S.lists : (item & IT_CULL) ? (const char *)S.cull : (const char *)S.nodes;
+        const unsigned idx = (item & IT_AFTER) ? (item & NODE_MASK) : (item & CULL_MASK);
+        const double2 *p = (const double2 *)(base + (size_t)idx * 64);
+        const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        rec[0] = q0.x; rec[1] = q0.y; rec[2] = q1.x; rec[3] = q1.y; rec[4] = q2.x; rec[5] = q2.y; rec[6] = q3.x; rec[7] = q3.y;
+    };
+    auto push = [&](unsigned item) __attribute__((always_inline)) {
+        if (sp < LDS_STACK) stk[sp][tid] = item;
+        else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = item;
+        sp++;
+    };
+    auto pop_next = [&]() __attribute__((always_inline)) {
+        if (sp == 0) phase = PH_SHADE; // the traversal is complete
+        else {
+            sp--;
+            cur = sp < LDS_STACK ? stk[sp][tid] : S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread];
+            load_rec(cur);
+            phase = PH_STEP;
+        }
+    };
+    auto start_traversal = [&](d3 o, d3 d) __attribute__((always_inline)) { // KdTree::check on the root (raytrace.cpp:46)
+        s[0] = o.x; s[1] = o.y; s[2] = o.z; v[0] = d.x; v[1] = d.y; v[2] = d.z;
+        par = (fabs(v[0]) < 1e-150 ? 1u : 0u) | (fabs(v[1]) < 1e-150 ? 2u : 0u) | (fabs(v[2]) < 1e-150 ? 4u : 0u);
+        inv[0] = (par & 1) ? 0.0 : 1.0 / v[0]; inv[1] = (par & 2) ? 0.0 : 1.0 / v[1]; inv[2] = (par & 4) ? 0.0 : 1.0 / v[2];
+        const double dlen2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        can_cull = dlen2 > 0.25 && dlen2 < 4.0;
+        best_t = 1e20; best_pos = -1; best_rank = 0; list_first = 0; list_end = 0;
+        sp = 0; flag = false;
+        cur = 0;
+        load_rec(cur);
+        phase = PH_STEP;
+        have_hit = true;
+        count(ST_RAYS, 1);
+    };
+
+    for (;;) {
+        int kind = -1;
+        if (phase == PH_STEP) kind = (cur & IT_AFTER) ? 2 : (cur & IT_CULL) ? 1 : 0;
+        else if (phase == PH_TRIS) kind = 3;
+        else if (phase == PH_SHADE) kind = 4;
+        const int c0 = __popcll(__ballot(kind == 0)), c1 = __popcll(__ballot(kind == 1)), c2 = __popcll(__ballot(kind == 2)),
+                  c3 = __popcll(__ballot(kind == 3)), c4 = __popcll(__ballot(kind == 4));
+        int pick = 0, most = c0;
+        if (c1 > most) { most = c1; pick = 1; }
+        if (c2 > most) { most = c2; pick = 2; }
+        if (c3 > most) { most = c3; pick = 3; }
+        if (c4 > most) { most = c4; pick = 4; }
+        if (most == 0) break; // every lane is done
+        pick = __builtin_amdgcn_readfirstlane(pick);
+
+        if (pick == 0) {
+            if (kind == 0) { // ---- enter a node (kdtree.cpp:111-141)
+                const double mi[3] = {rec[0], rec[1], rec[2]}, ma[3] = {rec[3], rec[4], rec[5]};
+                const double split = rec[6];
+                const long long w7 = __double_as_longlong(rec[7]);
+                const int right = (int)w7;
+                const unsigned info = (unsigned)(w7 >> 32);
+                const int node = (int)cur;
+                count(ST_VISITS, 1);
+                if (!aabb_hit(mi, ma, s, v)) pop_next();
+                else {
+                    const int axis = info & 3;
+                    const bool hasL = (info >> 2) & 1, hasR = right > 0;
+                    const double sw = axis == 0 ? s[0] : axis == 1 ? s[1] : s[2];
+                    const double vw = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
+                    int near = -1;
+                    unsigned farkind = 0; // 1: left child is the far one, 2: right child
+                    if (!hasL && !hasR) { /* leaf, or interior node whose triangles all straddle */ }
+                    else if (sw < split) { // kdtree.cpp:119-127
+                        if (hasL) near = node + 1;
+                        if (hasR && vw > 0) farkind = 2;
+                    } else if (sw > split) { // kdtree.cpp:128-136
+                        if (hasR) near = right;
+                        if (hasL && vw < 0) farkind = 1;
+                    } else { // kdtree.cpp:137-141: on the plane, only the child the ray points into
+                        if (vw < 0 && hasL) near = node + 1;
+                        else if (vw > 0 && hasR) near = right;
+                    }
+                    // the own list and the far child come after the near subtree; the frame's flag
+                    // travels in the item and the near subtree starts with a clean one
+                    const unsigned after = IT_AFTER | ((unsigned)flag << 30) | (farkind << 28) | (unsigned)node;
+                    flag = false;
+                    if (near >= 0) { push(after); cur = (unsigned)near; }
+                    else cur = after;
+                    load_rec(cur);
+                }
+            }
+        } else if (pick == 1) {
+            if (kind == 1) { // ---- one culling box of a long own list
+                const double lo[3] = {rec[0], rec[1], rec[2]}, hi[3] = {rec[3], rec[4], rec[5]};
+                const long long w7 = __double_as_longlong(rec[7]);
+                const int a = (int)w7, b = (int)(w7 >> 32);
+                count(ST_CULLS, 1);
+                if (!cull_hit(lo, hi, m2, s, inv, par)) pop_next();
+                else if (b < 0) { tb_first = a; tb_n = -b; phase = PH_TRIS; }
+                else { push(IT_CULL | (unsigned)b); cur = IT_CULL | (unsigned)a; load_rec(cur); }
+            }
+        } else if (pick == 2) {
+            if (kind == 2) { // ---- near child finished: own list (kdtree.cpp:122,131,137), then far child
+                const int node = (int)(cur & NODE_MASK);
+                const unsigned farkind = (cur >> 28) & 3;
+                const bool near_hit = flag;            // what the near child's check() returned
+                flag = ((cur >> 30) & 1) | near_hit;   // back in the enclosing frame
+                const long long w5 = __double_as_longlong(rec[5]), w6 = __double_as_longlong(rec[6]);
+                const int first = (int)w5, root = (int)(w5 >> 32), right = (int)w6, count_ = (int)(w6 >> 32);
+                count(ST_TRIS, (unsigned)count_);
+                if (farkind != 0 && !near_hit) push(farkind == 1 ? (unsigned)(node + 1) : (unsigned)right); // kdtree.cpp:124,133
+                if (count_ == 0) pop_next();
+                else {
+                    list_first = first; list_end = first + count_;
+                    if (root < 0 || !can_cull) { tb_first = first; tb_n = count_; phase = PH_TRIS; }
+                    else {
+                        m2 = 2.0 * list_margin(rec[0], rec[1], rec[2], rec[3], rec[4], s);
+                        cur = IT_CULL | (unsigned)root;
+                        load_rec(cur);
+                    }
+                }
+            }
+        } else if (pick == 3) {
+            if (kind == 3) { // ---- exact triangle tests (kdtree.cpp:101-107)
+                const d3 o = mk(s[0], s[1], s[2]), d = mk(v[0], v[1], v[2]);
+                for (int i = 0; i < tb_n; i++) {
+                    const TriRec &T = S.tris[tb_first + i];
+                    const double t = tri_hit(T, o, d);
+                    if (t > EPS) {
+                        const int rk = T.rank;
+                        // strict < keeps the earlier of two equal distances; inside one list "earlier"
+                        // is the lower rank, across lists it is the list visited first
+                        if (t < best_t || (t == best_t && best_pos >= list_first && best_pos < list_end && rk < best_rank)) {
+                            best_t = t; best_pos = tb_first + i; best_rank = rk;
+                        }
+                        if (t < 1e10) flag = true;
+                    }
+                }
+                count(ST_DONE, (unsigned)tb_n);
+                pop_next();
+            }
+        } else {
+            if (kind == 4) { // ---- traversal finished (or nothing started yet)
+                bool go_on = false, need_primary = false, need_work = false;
+                d3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+                if (have_hit) {
+                    have_hit = false;
+                    const d3 o = mk(s[0], s[1], s[2]), d = mk(v[0], v[1], v[2]);
+                    double ts;
+                    int ids;
+                    trace_spheres(S, o, d, ts, ids);
+                    count(ST_SPHS, (unsigned)S.n_sph);
+                    const double to = best_t;
+                    const int tpos = best_pos;
+                    const bool fo = to < 1e10, fs = ts < 1e10;
+                    if (TRACE) {
+                        if (fo && !(ts < to)) count(ST_SHADES, 1);
+                        tri_id[outk] = fo ? S.tris[tpos].gid : -1;
+                        tri_t[outk] = to;
+                        sph_id[outk] = fs ? ids : -1;
+                        sph_t[outk] = ts;
+                        need_work = true;
+                    } else if (fo || fs) { // raytrace.cpp:48-67
+                        d3 x, n, f, lig;
+                        int type;
+                        d3 thr = ls_get3(LS_THR);
+                        if (ts < to || !fo) {
+                            const SphGeom g = S.sph[ids];
+                            const SphShade sh = S.sshade[ids];
+                            x = o + d * ts;
+                            n = normv(x - mk(g.px, g.py, g.pz));
+                            f = ld3(sh.col); type = sh.type; lig = ld3(sh.lig);
+                            if (primary && sub == 0 && smp == 0 && prim) prim[outk] = -1 - ids;
+                        } else { // getn() returns the face normal (polygon.h:67-69)
+                            const TriShade *sh = S.tshade + tpos;
+                            x = o + d * to;
+                            n = ld3(sh->nc);
+                            f = ld3(sh->col); type = sh->type; lig = ld3(sh->lig);
+                            if (primary && sub == 0 && smp == 0 && prim) prim[outk] = S.tris[tpos].gid;
+                            count(ST_SHADES, 1);
+                        }
+                        const d3 nl = dot(n, d) < 0 ? n : n * -1.0;
+                        if (lig.x != 0 || lig.y != 0 || lig.z != 0) ls_put3(LS_ACC, ls_get3(LS_ACC) + mult(thr, lig));
+                        const double p = f.x > f.y && f.x > f.z ? f.x : f.y > f.z ? f.y : f.z; // raytrace.cpp:69
+                        ++depth;
+                        go_on = true;
+                        if (depth > P.hard_depth) go_on = false;
+                        else if (depth > P.rr_depth) { // raytrace.cpp:70-74
+                            if (P.rr_mode && rng_next(rng) < p) f = f * (1 / p);
+                            else go_on = false;
+                        }
+                        if (go_on) {
+                            thr = mult(thr, f);
+                            if (type == RT_DIFF) { // raytrace.cpp:77-82
+                                const double r1 = 2 * M_PI * rng_next(rng), r2 = rng_next(rng), r2s = sqrt(r2);
+                                const d3 w = nl, u = normv(cross(fabs(w.x) > .1 ? mk(0, 1, 0) : mk(1, 0, 0), w)), vv = cross(w, u);
+                                double sn, cs;
+                                sincos_2pi(r1, sn, cs);
+                                rd = normv(u * cs * r2s + vv * sn * r2s + w * sqrt(1 - r2));
+                                ro = x - d * EPS;
+                            } else if (type == RT_SPEC) { // raytrace.cpp:83-84
+                                rd = d - n * 2.0 * dot(n, d);
+                                ro = x - d * EPS;
+                            } else { // raytrace.cpp:86-94
+                                const d3 reflo = x - d * EPS, refld = d - n * 2.0 * dot(n, d);
+                                const double nc = 1, nt = 1.7, nnt = into ? nc / nt : nt / nc, ddn = dot(d, nl);
+                                const double cos2t = 1 - nnt * nnt * (1 - ddn * ddn);
+                                if (cos2t < 0) { ro = reflo; rd = refld; } // total internal reflection
+                                else {
+                                    const d3 tdir = normv(d * nnt - n * ((into ? 1 : -1) * (ddn * nnt + sqrt(cos2t))));
+                                    const double a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(tdir, n));
+                                    const double Re = R0 + (1 - R0) * c * c * c * c * c, Tr = 1 - Re, Pp = .25 + .5 * Re, RP = Re / Pp,
+                                                 TP = Tr / (1 - Pp);
+                                    const d3 refro = x + d * EPS;
+                                    if (depth > P.split_depth) {
+                                        if (rng_next(rng) < Pp) { thr = thr * RP; ro = reflo; rd = refld; }
+                                        else { thr = thr * TP; ro = refro; rd = tdir; into = !into; }
+                                    } else { // both branches: park the reflection, follow the refraction first
+                                        Pending &q = pend[np++];
+                                        q.o = reflo; q.d = refld; q.thr = thr * Re; q.depth = depth; q.into = into;
+                                        thr = thr * Tr; ro = refro; rd = tdir; into = !into;
+                                    }
+                                }
+                            }
+                            ls_put3(LS_THR, thr);
+                        }
+                    } else if (primary && sub == 0 && smp == 0 && prim) prim[outk] = RT_ID_MISS;
+                    primary = false;
+                    if (!TRACE && !go_on) {
+                        if (np > 0) { // resume a parked glass branch
+                            const Pending &q = pend[--np];
+                            ro = q.o; rd = q.d; ls_put3(LS_THR, q.thr); depth = q.depth; into = q.into != 0;
+                            go_on = true;
+                        } else { // the path is complete (raytrace.cpp:203-205)
+                            d3 rsum = ls_get3(LS_RSUM) + ls_get3(LS_ACC) * (1.0 / samps);
+                            if (++smp == samps) {
+                                smp = 0;
+                                const d3 col = ls_get3(LS_COL) + mk(clamp01(rsum.x), clamp01(rsum.y), clamp01(rsum.z)) * .25;
+                                rsum = mk(0, 0, 0);
+                                if (++sub == 4) {
+                                    rgb[3 * (size_t)outk] = col.x; rgb[3 * (size_t)outk + 1] = col.y; rgb[3 * (size_t)outk + 2] = col.z;
+                                    need_work = true;
+                                } else ls_put3(LS_COL, col);
+                            }
+                            ls_put3(LS_RSUM, rsum);
+                            need_primary = !need_work;
+                        }
+                    }
+                } else need_work = true; // first iteration: nothing traced yet
+
+                // ---- lanes without work take the next pixel (or ray) from the shared counter
+                for (;;) {
+                    const unsigned long long want = __ballot(need_work);
+                    if (want == 0) break;
+                    unsigned base = 0;
+                    const int leader = __ffsll((long long)want) - 1;
+                    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(want));
+                    base = __shfl(base, leader, 64);
+                    if (need_work) {
+                        const unsigned w = base + (unsigned)__popcll(want & lane_lt);
+                        if (w >= n_work) { need_work = false; phase = PH_DONE; }
+                        else if (TRACE) { outk = w; need_work = false; go_on = true; ro = ld3(rays + 6 * (size_t)w); rd = ld3(rays + 6 * (size_t)w + 3); }
+                        else {
+                            const unsigned blk = w >> 6, li = w & 63;
+                            int lo = 0, hi = n_tiles - 1; // last tile whose first block is <= blk
+                            while (lo < hi) {
+                                const int mid = (lo + hi + 1) >> 1;
+                                if ((unsigned)tiles[mid].blk_first <= blk) lo = mid; else hi = mid - 1;
+                            }
+                            const DevTile T = tiles[lo];
+                            const int b = (int)blk - T.blk_first;
+                            const int lrow = (b / T.blk_cols) * 8 + (int)(li >> 3), lcol = (b % T.blk_cols) * 8 + (int)(li & 7);
+                            if (lrow < T.rows && lcol < T.cols) { // ragged edge blocks have unused lanes
+                                pxy = ((unsigned)(T.x0 + lrow) << 16) | (unsigned)(T.y0 + lcol);
+                                outk = (unsigned)(T.out_off + (long long)lrow * T.cols + lcol);
+                                sub = 0; smp = 0;
+                                ls_put3(LS_COL, mk(0, 0, 0)); ls_put3(LS_RSUM, mk(0, 0, 0));
+                                need_work = false;
+                                need_primary = true;
+                            }
+                        }
+                    }
+                }
+                if (!TRACE && need_primary) { // raytrace.cpp:196-203
+                    const int sx = sub >> 1, sy = sub & 1, px = (int)(pxy >> 16), py = (int)(pxy & 0xFFFF);
+                    const unsigned long long path =
+                        ((((unsigned long long)px * (unsigned long long)sizey + (unsigned long long)py) * 2 + sx) * 2 + sy) *
+                            (unsigned long long)samps + smp;
+                    rng = path_state(P.seed, path);
+                    double dx = 0, dy = 0;
+                    if (P.jitter) {
+                        const double r1 = 2 * rng_next(rng); dx = r1 < 1 ? sqrt(r1) - 1 : 1 - sqrt(2 - r1);
+                        const double r2 = 2 * rng_next(rng); dy = r2 < 1 ? sqrt(r2) - 1 : 1 - sqrt(2 - r2);
+                    }
+                    const d3 dd = ccx * (((sx + .5 + dx) / 2 + px) / sizex - .5) + ccy * (((sy + .5 + dy) / 2 + py) / sizey - .5) + camd;
+                    // raytrace.cpp:203: d is normalised in place before the origin is formed
+                    // (g++ evaluates the constructor arguments right to left)
+                    rd = normv(dd);
+                    ro = camo + rd * 140.0;
+                    ls_put3(LS_ACC, mk(0, 0, 0)); ls_put3(LS_THR, mk(1, 1, 1));
+                    depth = 0; into = true; np = 0; primary = true;
+                    go_on = true;
+                }
+                if (go_on) start_traversal(ro, rd);
+            }
+        }
     }
-    wave_add_stats(st, gstats);
+
+    // ---- work counters: per-lane totals -> wavefront sum -> one atomic per counter
+#pragma unroll
+    for (int k = 0; k < N_STATS; k++) {
+        unsigned long long x = sacc[k][tid];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0 && x) atomicAdd(gstats + k, x);
+    }
 }
 
 __global__ void k_fp64(int op, long long n, const double *a, const double *b, double *out) {
@@ -606,7 +710,7 @@ struct rt_scene {
     int dev = 0;
     DevScene d{};
     void *nodes = nullptr, *first = nullptr, *cull = nullptr, *tris = nullptr, *tshade = nullptr, *sph = nullptr, *sshade = nullptr;
-    void *ovf = nullptr;
+    void *ovf = nullptr, *lstate = nullptr;
     int tree_depth = 0;
     int grid = 0;               // persistent workgroups
     unsigned *d_counter = nullptr; // [0] block counter
@@ -638,6 +742,7 @@ int cull_rec(std::vector<CullRec> &out, std::vector<CullTri> &bt, int a, int b, 
             clo[k] = std::min(clo[k], bt[i].c[k]); chi[k] = std::max(chi[k], bt[i].c[k]);
         }
     for (int k = 0; k < 3; k++) { out[me].lo[k] = lo[k]; out[me].hi[k] = hi[k]; }
+    out[me].pad = 0;
     if (b - a <= CULL_LEAF) {
         out[me].a = first + a;
         out[me].b = -(b - a);
@@ -657,7 +762,7 @@ int cull_rec(std::vector<CullRec> &out, std::vector<CullTri> &bt, int a, int b, 
     return me;
 }
 
-void build_cull(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<CullRec> &cull, ListInfo &li,
+void build_cull(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<CullRec> &cull, ListRec &li,
                 int &max_depth) {
     std::vector<CullTri> bt((size_t)count);
     double lmax2 = 0;
@@ -740,6 +845,7 @@ int upload(void **dst, const std::vector<T> &src) {
 int check_params(const rt_camera *cam, const rt_params *p) {
     if (!cam || !p) return fail(RT_E_INVALID, "camera or params is NULL");
     if (cam->sizex < 1 || cam->sizey < 1) return fail(RT_E_INVALID, "image size %d x %d", cam->sizex, cam->sizey);
+    if (cam->sizex > 65536 || cam->sizey > 65536) return fail(RT_E_LIMIT, "image size %d x %d exceeds 65536", cam->sizex, cam->sizey);
     if (p->samps < 1) return fail(RT_E_INVALID, "samps must be >= 1");
     if (p->split_depth < 0 || p->split_depth > MAX_SPLIT) return fail(RT_E_LIMIT, "split_depth must be in [0,%d]", MAX_SPLIT);
     if (p->rr_depth < 0) return fail(RT_E_INVALID, "rr_depth must be >= 0");
@@ -786,7 +892,7 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         d.blk_cols = (t.cols + 7) / 8;
         off += (long long)t.rows * t.cols;
         blocks += (long long)((t.rows + 7) / 8) * d.blk_cols;
-        if (blocks > 0x7FFFFFF0LL) return fail(RT_E_LIMIT, "too many pixel blocks in one launch");
+        if (blocks > 0x1FFFFFFLL) return fail(RT_E_LIMIT, "too many pixel blocks in one launch");
     }
     HIP_TRY(hipSetDevice(s->dev));
     if (n_tiles > s->tiles_cap) {
@@ -805,8 +911,9 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     const DevCamera dc = make_camera(cam);
     const int grid = (int)std::min<long long>(s->grid, (blocks + 3) / 4);
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(k_render, dim3(grid), dim3(BLOCK), 0, stream, s->d, dc, *p, (const DevTile *)s->d_tiles, n_tiles,
-                       (unsigned)blocks, s->d_counter, d_rgb, d_prim, s->d_stats);
+    hipLaunchKernelGGL(k_main<false>, dim3(grid), dim3(BLOCK), 0, stream, s->d, dc, *p, (const DevTile *)s->d_tiles, n_tiles,
+                       (unsigned)(blocks * 64), s->d_counter, d_rgb, d_prim, (const double *)nullptr, (int *)nullptr,
+                       (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     s->timed = true;
@@ -850,7 +957,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     HIP_TRY(hipSetDevice(dev));
 
     std::vector<NodeRec> nodes((size_t)D->n_nodes);
-    std::vector<ListInfo> lists((size_t)D->n_nodes);
+    std::vector<ListRec> lists((size_t)D->n_nodes);
     std::vector<CullRec> cull;
     std::vector<int> order((size_t)D->n_list); // device position -> entry of list_tri
     for (int i = 0; i < D->n_list; i++) order[i] = i;
@@ -860,11 +967,13 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         for (int k = 0; k < 3; k++) { n.mi[k] = D->node_box[6 * i + k]; n.ma[k] = D->node_box[6 * i + 3 + k]; }
         n.split = D->node_split[i];
         n.right = D->node_right[i] > 0 ? D->node_right[i] : 0;
-        n.info = (unsigned)D->node_axis[i] | (D->node_left[i] >= 0 ? 4u : 0u) | ((unsigned)D->node_count[i] << 3);
-        ListInfo &li = lists[i];
+        n.info = (unsigned)D->node_axis[i] | (D->node_left[i] >= 0 ? 4u : 0u);
+        ListRec &li = lists[i];
         li.first = D->node_first[i];
         li.root = -1;
-        li.c[0] = li.c[1] = li.c[2] = 0; li.k2 = 0; li.r2 = 0;
+        li.right = n.right;
+        li.count = D->node_count[i];
+        li.c[0] = li.c[1] = li.c[2] = 0; li.k2 = 0; li.r2 = 0; li.pad = 0;
         if (D->node_count[i] > CULL_MIN) build_cull(D, D->node_first[i], D->node_count[i], order, cull, li, cull_depth);
     }
     if (cull.size() > 0x7FFFFFF0ull) return fail(RT_E_LIMIT, "culling hierarchy too large");
@@ -918,7 +1027,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     hipDeviceProp_t pr;
     int per_cu = 0;
     if (hipGetDeviceProperties(&pr, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, BLOCK, 0) != hipSuccess || per_cu < 1)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_main<false>, BLOCK, 0) != hipSuccess || per_cu < 1)
         per_cu = 2;
     s->grid = pr.multiProcessorCount * per_cu;
     const int n_threads = s->grid * BLOCK;
@@ -926,6 +1035,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK : 0;
     hipError_t e = hipSuccess;
     if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_threads * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&s->lstate, (size_t)LS_SLOTS * n_threads * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_counter, 16);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
@@ -936,13 +1046,14 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         return fail(RT_E_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
     }
     s->d.nodes = (const NodeRec *)s->nodes;
-    s->d.lists = (const ListInfo *)s->first;
+    s->d.lists = (const ListRec *)s->first;
     s->d.cull = (const CullRec *)s->cull;
     s->d.tris = (const TriRec *)s->tris;
     s->d.tshade = (const TriShade *)s->tshade;
     s->d.sph = (const SphGeom *)s->sph;
     s->d.sshade = (const SphShade *)s->sshade;
     s->d.ovf = (unsigned *)s->ovf;
+    s->d.lstate = (double *)s->lstate;
     s->d.n_nodes = D->n_nodes;
     s->d.n_tris = D->n_tris;
     s->d.n_sph = D->n_spheres;
@@ -955,7 +1066,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->nodes, s->first, s->cull, s->tris, s->tshade, s->sph, s->sshade, s->ovf, s->d_counter, s->d_stats, s->d_tiles};
+    void *ptrs[] = {s->nodes, s->first, s->cull, s->tris, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->d_counter, s->d_stats, s->d_tiles};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -1022,6 +1133,7 @@ int rt_render_tile(rt_scene *s, const rt_camera *cam, const rt_tile *tile, const
 int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, double *tri_t, int32_t *sph_id, double *sph_t,
                   rt_stats *stats) {
     if (!s) return fail(RT_E_INVALID, "scene is NULL");
+    if (n > 0x7FFFFFF0LL) return fail(RT_E_LIMIT, "too many rays in one call");
     if (n < 0 || (n > 0 && (!rays || !tri_id || !tri_t || !sph_id || !sph_t))) return fail(RT_E_INVALID, "bad ray buffers");
     HIP_TRY(hipSetDevice(s->dev));
     if (n == 0) {
@@ -1037,11 +1149,15 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) e = hipMalloc((void **)&d_si, (size_t)n * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(s->d_counter, 0, 16);
     if (e == hipSuccess) {
         const long long want = (n + BLOCK - 1) / BLOCK;
         const int grid = (int)std::min<long long>(s->grid, want); // stay within the overflow stack's thread count
-        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(BLOCK), 0, nullptr, s->d, (long long)n, (const double *)d_rays, d_ti, d_tt,
-                           d_si, d_st, s->d_stats);
+        rt_params none = {1, 0, 0, 0, 1, 0, 0};
+        DevCamera nocam = {};
+        hipLaunchKernelGGL(k_main<true>, dim3(grid), dim3(BLOCK), 0, nullptr, s->d, nocam, none, (const DevTile *)nullptr, 0,
+                           (unsigned)n, s->d_counter, (double *)nullptr, (int *)nullptr, (const double *)d_rays, d_ti, d_tt, d_si,
+                           d_st, s->d_stats);
         e = hipGetLastError();
         s->last_stream = nullptr;
     }

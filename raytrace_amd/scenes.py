@@ -237,7 +237,7 @@ def sponza_class(n_tris=262267, sizex=2160, sizey=3840, seed=3, detail=1.0):
     which absorbs the remainder so the total is exact."""
     rs = np.random.RandomState(seed)
     q = lambda v: max(2, int(round(v * detail)))  # noqa: E731
-    X0, X1, Y0, Y1, Z0, Z1 = -20.0, 120.0, 0.0, 80.0, 0.0, 262.0
+    X0, X1, Y0, Y1, Z0, Z1 = -20.0, 120.0, 0.0, 80.0, 0.0, 280.0  # every camera ray starts inside (z <= 275.6)
     W, Hh, Ln = X1 - X0, Y1 - Y0, Z1 - Z0
     meshes = []
     stone, warm, dark = (.72, .68, .6), (.8, .6, .45), (.35, .3, .28)
