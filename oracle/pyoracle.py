@@ -90,6 +90,8 @@ def lib():
                                       C.c_int, _dp, _ip, C.POINTER(OStats), C.c_int]
         L.orc_radiance.argtypes = [C.c_void_p, C.POINTER(OParams), C.c_int, _dp, _dp, C.POINTER(OStats)]
         L.orc_draw_pixels.argtypes = [_dp, C.c_size_t, C.POINTER(C.c_ubyte)]
+        L.orc_check_aabb.argtypes = [_dp, _dp]
+        L.orc_primary_ray.argtypes = [_dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -209,6 +211,18 @@ class OracleScene:
         st = OStats()
         self.L.orc_radiance(self.h, C.byref(params), r.shape[0], _d(r), _d(rgb), C.byref(st))
         return rgb, st.as_dict()
+
+
+def check_aabb(box, ray):
+    b = np.ascontiguousarray(box, dtype=np.float64).reshape(6)
+    r = np.ascontiguousarray(ray, dtype=np.float64).reshape(6)
+    return bool(lib().orc_check_aabb(_d(b), _d(r)))
+
+
+def primary_ray(camo, d):
+    out = np.zeros(6)
+    lib().orc_primary_ray(_d(_c3(camo)), _d(_c3(d)), _d(out))
+    return out
 
 
 def camera_basis(cam):

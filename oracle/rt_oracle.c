@@ -406,6 +406,13 @@ double orc_sph_intersect(const oscene *sc, int i, const double *ray) {
     return sph_intersect(&sc->sphs[i], &r);
 }
 
+int orc_check_aabb(const double *box, const double *ray) {
+    onode b; memset(&b, 0, sizeof(b));
+    for (int k = 0; k < 3; k++) { b.mi[k] = box[k]; b.ma[k] = box[3 + k]; }
+    ray_t r = {V(ray[0], ray[1], ray[2]), V(ray[3], ray[4], ray[5])};
+    return check_aabb(&b, &r);
+}
+
 /* ------------------------------------------------------------------ RNG policy */
 
 /* libc drand48 recurrence: X' = (0x5DEECE66D X + 0xB) mod 2^48, value X'/2^48. */
@@ -526,6 +533,13 @@ void orc_camera_basis(const ocamera *cam, double *camd, double *cx, double *cy) 
     v3 vy = V(cam->sizey * .5035 / cam->sizex, 0, 0), vx = vscale(vnorm(vcross(vy, d)), -.5035);
     camd[0] = d.x; camd[1] = d.y; camd[2] = d.z;
     cx[0] = vx.x; cx[1] = vx.y; cx[2] = vx.z; cy[0] = vy.x; cy[1] = vy.y; cy[2] = vy.z;
+}
+
+/* The camera ray of raytrace.cpp:203 for an (unnormalised) direction d, as render_pixel forms it. */
+void orc_primary_ray(const double *camo, const double *d, double *out) {
+    v3 dn = vnorm(V(d[0], d[1], d[2]));
+    v3 o = vadd(V(camo[0], camo[1], camo[2]), vscale(dn, 140));
+    out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = dn.x; out[4] = dn.y; out[5] = dn.z;
 }
 
 /* One pixel (row x, column y) of raytrace.cpp:196-205. */

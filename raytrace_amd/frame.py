@@ -87,7 +87,8 @@ class FrameRenderer:
         """Asynchronous: this rank's tiles, one kernel launch on torch's current stream."""
         if not self.my_tiles:
             return
-        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        # the kernel goes on torch's current stream so that torch-side events and collectives order with it
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
         self.scene.render_tiles_device(self.cam, self.params, self.my_tiles, self.local.data_ptr(),
                                        self.local_ids.data_ptr() if self.want_ids else None, stream)
 

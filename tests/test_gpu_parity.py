@@ -65,6 +65,45 @@ def test_trace_rays_bit_exact(world, name):
     assert (tid >= 0).sum() > 0 or name == "cornell"
 
 
+@pytest.mark.parametrize("name", ["tiny0", "tiny5", "cornell", "bunny2k", "sponza12k"])
+def test_trace_rays_match_reference_golden_vectors(ra, name):
+    """The HIP path against vectors recorded from the reference's own object code (tests/golden)."""
+    from helpers import load_fixture, scene_from_fixture
+    fx = load_fixture(name)
+    hs = ra.HostScene(scene_from_fixture(fx))
+    dev = ra.DeviceScene(hs, 0)
+    tid, tt, sid, st, _ = dev.trace_rays(fx["rays"])
+    dev.close()
+    assert np.array_equal(tid, fx["trace_tri_id"])
+    assert np.array_equal(tt, fx["trace_tri_t"])
+    assert np.array_equal(sid, fx["trace_sph_id"])
+    assert np.array_equal(st, fx["trace_sph_t"])
+
+
+def test_trace_rays_non_unit_directions(world):
+    """Directions far from unit length take the full own-list scan instead of the culled one; the
+    answers must still be the reference's (distances scale with 1/|d|)."""
+    w = world["bunny5k"]
+    rays = random_rays(21, 3000, w["center"], w["spread"])
+    rays[:1000, 3:] *= 7.5
+    rays[1000:2000, 3:] *= 0.01
+    tid, tt, sid, st, stats = w["dev"].trace_rays(rays)
+    otid, ott, osid, ost, ostats = w["orc"].trace(rays)
+    assert np.array_equal(tid, otid) and np.array_equal(tt, ott)
+    assert np.array_equal(sid, osid) and np.array_equal(st, ost)
+    assert stats["tri_tests_done"] > 0.5 * stats["tri_tests"]  # mostly full scans
+
+
+def test_culling_skips_most_tests_and_keeps_answers(world):
+    w = world["sponza40k"]
+    rays = random_rays(33, 4000, w["center"], w["spread"])
+    tid, tt, _, _, stats = w["dev"].trace_rays(rays)
+    otid, ott, _, _, ostats = w["orc"].trace(rays)
+    assert np.array_equal(tid, otid) and np.array_equal(tt, ott)
+    assert stats["tri_tests"] == ostats["tri_tests"]            # the reference's count is still reported
+    assert stats["tri_tests_done"] < 0.1 * stats["tri_tests"]   # but only a fraction is executed
+
+
 def test_trace_rays_axis_aligned_and_on_plane(world):
     """Rays parallel to the axes, starting on split planes and box faces: the s[w]==split branch
     (kdtree.cpp:137-141) and the |v|>eps gates of check_aabb (kdtree.h:64)."""

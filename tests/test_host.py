@@ -1,0 +1,154 @@
+"""Host library: builder properties, scene-file / OBJ readers, tone mapping, BMP output."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+
+def test_tree_properties(ra):
+    from raytrace_amd import scenes
+    sc = scenes.sponza_class(20000, detail=0.18)
+    hs = ra.HostScene(sc)
+    t = hs.tree_arrays()
+    n = len(t["axis"])
+    assert sorted(t["list"].tolist()) == list(range(hs.num_tris))          # every triangle in exactly one own list
+    assert np.array_equal(t["first"], np.concatenate([[0], np.cumsum(t["count"])[:-1]]))
+    has_l = t["left"] >= 0
+    assert np.array_equal(t["left"][has_l], np.nonzero(has_l)[0] + 1)      # pre-order: left child is node + 1
+    leaf = (t["left"] < 0) & (t["right"] < 0) & (t["count"] < 4)
+    assert leaf.sum() > 0
+    inner = ~leaf
+    ax = t["axis"][inner]
+    box = t["box"][inner]
+    mid = (box[np.arange(len(ax)), ax] + box[np.arange(len(ax)), 3 + ax]) * 0.5
+    assert np.array_equal(t["split"][inner], mid)                          # kdtree.cpp:82
+    kids = np.concatenate([t["left"][has_l], t["right"][t["right"] >= 0]])
+    par = np.concatenate([np.nonzero(has_l)[0], np.nonzero(t["right"] >= 0)[0]])
+    assert np.array_equal(t["axis"][kids], (t["axis"][par] + 1) % 3)       # kdtree.cpp:94-95
+    assert t["axis"][0] == 0 and n == len(set(kids.tolist())) + 1
+
+
+def test_empty_scene_has_one_empty_leaf(ra):
+    hs = ra.HostScene({"meshes": [], "spheres": []})
+    t = hs.tree_arrays()
+    assert len(t["axis"]) == 1 and t["count"][0] == 0 and t["depth"] == 1
+    assert np.array_equal(t["box"][0], [1e10] * 3 + [-1e10] * 3)           # kdtree.h:36-40
+
+
+def test_tonemap_matches_drawpixel(ra, po):
+    rs = np.random.RandomState(0)
+    rgb = np.concatenate([rs.uniform(-0.2, 1.3, (5000, 3)), [[0, 0, 0], [1, 1, 1], [0.5, 0.25, 2.0]]])
+    got = ra.tonemap(rgb)
+    assert np.array_equal(got, po.draw_pixels(rgb))
+    c = np.clip(rgb, 0, 1)
+    want = (c ** (1 / 2.2) * 255 + .5).astype(np.int64)[:, ::-1]           # raytrace.cpp:33-39, BGR order
+    assert np.abs(got.astype(np.int64) - want).max() <= 1                  # libm pow vs numpy pow: last-ulp cases only
+
+
+def test_bmp_roundtrip(ra, tmp_path):
+    rs = np.random.RandomState(1)
+    img = rs.randint(0, 256, (5, 7, 3)).astype(np.uint8)                    # 7*3 = 21 bytes per row -> padded to 24
+    p = tmp_path / "o.bmp"
+    ra.write_bmp(p, img)
+    raw = p.read_bytes()
+    assert raw[:2] == b"BM" and struct.unpack("<I", raw[2:6])[0] == len(raw) == 54 + 24 * 5
+    w, h, planes, bpp = struct.unpack("<iiHH", raw[18:30])
+    assert (w, h, planes, bpp) == (7, 5, 1, 24)
+    rows = [np.frombuffer(raw[54 + 24 * r: 54 + 24 * r + 21], np.uint8).reshape(7, 3) for r in range(5)]
+    assert np.array_equal(np.array(rows[::-1]), img)                        # stored bottom-up
+
+
+def test_scene_file_roundtrip(ra, tmp_path):
+    from raytrace_amd import scenes
+    sc = scenes.cornell_demo(sizex=30, sizey=40)
+    path = scenes.write_scene_files(sc, str(tmp_path), c_samps=3, g_samps=5)
+    a = ra.HostScene.from_file(path)
+    b = ra.HostScene(sc)
+    st = a.settings
+    assert (st.sizex, st.sizey, st.c_samps, st.g_samps, st.num_per_node, st.cu_stack_size) == (30, 40, 3, 5, 1, 4096)
+    assert list(st.view) == list(sc["camera"]["o"]) and list(st.dir) == list(sc["camera"]["d"])
+    ta, tb = a.tree_arrays(), b.tree_arrays()
+    for k in ta:
+        assert np.array_equal(ta[k], tb[k]), k
+    da, db = a.desc.contents, b.desc.contents
+    assert da.n_spheres == db.n_spheres == 9
+    for f in ("sph_rad", "sph_pos", "sph_lig", "sph_col", "tri_col", "tri_lig"):
+        n = da.n_spheres * (1 if f == "sph_rad" else 3) if f.startswith("sph") else da.n_tris * 3
+        assert np.array_equal(np.ctypeslib.as_array(getattr(da, f), shape=(n,)), np.ctypeslib.as_array(getattr(db, f), shape=(n,))), f
+    assert np.array_equal(np.ctypeslib.as_array(da.tri_type, shape=(da.n_tris,)), np.ctypeslib.as_array(db.tri_type, shape=(db.n_tris,)))
+
+
+OBJ = """# cube corner
+mtllib m.mtl
+v 0 0 0
+v 1 0 0
+v 0 1 0
+v 0 0 1
+vn 0 0 1
+vt 0.5 0.5
+usemtl red
+f 1 2 3
+usemtl blue
+f 1/1 2/1 4/1
+f 1//1 3//1 4//1
+usemtl nosuch
+f 2/1/1 3/1/1 4/1/1 1/1/1
+"""
+MTL = """newmtl red
+Kd 1 0 0
+Ks 0 1 0
+newmtl blue
+Ka 9 9 9
+Kd 0 0 1
+Ks 0.5 0.5 0.5
+"""
+
+
+def test_obj_reader(ra, tmp_path):
+    (tmp_path / "a.obj").write_text(OBJ)
+    (tmp_path / "m.mtl").write_text(MTL)
+    hs = ra.HostScene()
+    hs.add_obj_file(tmp_path / "a.obj", 2.0, (10, 20, 30), (0, 0, 90), (0, 0, 0), (.3, .3, .3), ra.capi.RT_DIFF)
+    hs.add_obj_file(tmp_path / "a.obj", 1.0, (0, 0, 0), (0, 0, 0), (0, 0, 0), (.3, .3, .3), ra.capi.RT_SPEC)
+    hs.build()
+    t = hs.tree_arrays()
+    assert hs.num_tris == 8                                                 # the 4th vertex of the last face is dropped
+    d = hs.desc.contents
+    col = np.ctypeslib.as_array(d.tri_col, shape=(8, 3))
+    # diffuse object: Kd; unknown material falls back to the object's colour (object.cpp:44-49, 75-106)
+    assert np.array_equal(col[:4], [[1, 0, 0], [0, 0, 1], [0, 0, 1], [.3, .3, .3]])
+    assert np.array_equal(col[4:], [[0, 1, 0], [.5, .5, .5], [.5, .5, .5], [.3, .3, .3]])  # specular object: Ks
+    # scale 2, rotate 90 degrees about z (x -> y, y -> -x), translate (object.cpp:22-23, 138-140)
+    v = t["verts"][0].reshape(3, 3)
+    want = np.array([[0, 0, 0], [0, 2, 0], [-2, 0, 0]]) + [10, 20, 30]
+    assert np.abs(v - want).max() < 1e-12
+    assert np.array_equal(t["verts"][4].reshape(3, 3), [[0, 0, 0], [1, 0, 0], [0, 1, 0]])
+
+
+def test_reader_errors(ra, tmp_path):
+    hs = ra.HostScene()
+    with pytest.raises(ra.capi.RtError, match="Can't open"):
+        hs.add_obj_file(tmp_path / "missing.obj", 1, (0, 0, 0), (0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    with pytest.raises(ra.capi.RtError, match="Error face"):
+        hs.add_obj_file(tmp_path / "bad.obj", 1, (0, 0, 0), (0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    (tmp_path / "neg.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -3 -2 -1\n")
+    with pytest.raises(ra.capi.RtError, match="Error face"):  # negative indices are unsupported there too
+        hs.add_obj_file(tmp_path / "neg.obj", 1, (0, 0, 0), (0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    (tmp_path / "t.txt").write_text("0\n1\n1 0 0 0 0 0 0 1 1 1 DIFF\n10 10 1\n")
+    with pytest.raises(ra.capi.RtError, match="settings"):
+        ra.HostScene.from_file(tmp_path / "t.txt")
+    with pytest.raises(ra.capi.RtError):
+        ra.HostScene().desc  # not built yet
+
+
+def test_scene_generators_hit_their_triangle_counts():
+    from raytrace_amd import scenes
+    assert scenes.num_tris(scenes.bunny_class(69451)) == 69451
+    assert scenes.num_tris(scenes.sponza_class(262267)) == 262267
+    assert scenes.num_tris(scenes.sponza_class(30000, detail=0.25)) == 30000
+    s = scenes.random_spheres(10000)
+    assert len(s["spheres"]) == 10000 and not s["meshes"]
+    a, b = scenes.sponza_class(30000, detail=0.25), scenes.sponza_class(30000, detail=0.25)
+    assert all(np.array_equal(x["verts"], y["verts"]) for x, y in zip(a["meshes"], b["meshes"]))  # deterministic

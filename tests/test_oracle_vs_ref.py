@@ -1,0 +1,64 @@
+"""The oracle against the reference's own object code (oracle/_ref), live, on inputs beyond the
+committed fixtures.  Skipped where _ref was not built (it needs the reference checkout)."""
+import numpy as np
+import pytest
+
+from conftest import random_rays
+
+
+@pytest.fixture(scope="module")
+def ref(po):
+    if not po.ref_available():
+        pytest.skip("oracle/_ref/libref_l3.so not built")
+    return po
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_soups(ref, seed):
+    from raytrace_amd import scenes
+    sc = scenes.tiny_mixed(seed, n_tris=30 + 150 * seed, n_sph=3 + 2 * seed)
+    orc, rf = ref.OracleScene(sc), ref.RefScene(sc)
+    a, b = orc.tree_dump(), rf.tree_dump()
+    for k in b:
+        assert np.array_equal(a[k], b[k]), k
+    rays = random_rays(seed, 2500, np.zeros(3), 15.0)
+    got, want = orc.trace(rays), rf.trace(rays)
+    for x, y in zip(got[:4], want):
+        assert np.array_equal(x, y)
+
+
+def test_procedural_scenes(ref):
+    from raytrace_amd import scenes
+    for sc, ctr, spr in ((scenes.bunny_class(9000), np.array([50, 30, 80.0]), 50.0),
+                         (scenes.sponza_class(25000, detail=0.2), np.array([50, 40, 140.0]), 70.0)):
+        orc, rf = ref.OracleScene(sc), ref.RefScene(sc)
+        a, b = orc.tree_dump(), rf.tree_dump()
+        for k in b:
+            assert np.array_equal(a[k], b[k]), k
+        rays = random_rays(4, 1500, ctr, spr)
+        got, want = orc.trace(rays), rf.trace(rays)
+        for x, y in zip(got[:4], want):
+            assert np.array_equal(x, y)
+
+
+def test_degenerate_inputs(ref):
+    """Empty scene, fewer than 4 triangles (single leaf), duplicate and zero-area triangles."""
+    from raytrace_amd import scenes
+    tri = np.array([[-5, -5, 0, 5, -5, 0, 0, 5, 0.0]])
+    flat = np.array([[0, 0, 1, 1, 1, 1, 2, 2, 1.0]])  # zero area: nc is NaN, never hit
+    cases = [
+        {"meshes": [], "spheres": []},
+        {"meshes": [scenes._mesh(tri, (.5, .5, .5))], "spheres": []},
+        {"meshes": [scenes._mesh(np.repeat(tri, 7, 0), (.5, .5, .5)), scenes._mesh(flat, (.1, .1, .1))],
+         "spheres": [scenes._sphere(2, (0, 0, 3), (0, 0, 0), (.5, .5, .5), 0)] * 2},
+    ]
+    rays = random_rays(6, 400, np.zeros(3), 8.0)
+    rays = np.concatenate([rays, [[0, 0, 10, 0, 0, -1.0], [0, 0, -10, 0, 0, 1.0]]])
+    for sc in cases:
+        orc, rf = ref.OracleScene(sc), ref.RefScene(sc)
+        a, b = orc.tree_dump(), rf.tree_dump()
+        for k in b:
+            assert np.array_equal(a[k], b[k]), k
+        got, want = orc.trace(rays), rf.trace(rays)
+        for x, y in zip(got[:4], want):
+            assert np.array_equal(x, y)
