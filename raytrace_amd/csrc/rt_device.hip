@@ -18,11 +18,11 @@
 // Layout in HBM (built by rt_upload_scene):
 //   NodeRec   64 B, 64-B aligned: box (48), split (8), right child (4), info (4: axis, has-left,
 //             own-list length).  Nodes are in pre-order so the left child is node+1.
-//   ListInfo  48 B per node: start of the node's own list, and for long lists the root of a
-//             culling hierarchy plus the data for its safety margin
+//   ListRec   64 B per node: start and length of the node's own list, and for long lists the root
+//             of a culling hierarchy plus the data for its safety margin
 //   TriRec    80 B, 16-B aligned, grouped by own list (each triangle is in exactly one list), so a
 //             node's list is a contiguous run: p0, E1 = p1-p0, E2 = p2-p0, global id, list rank
-//   CullRec   64 B: box + two children, or a run of <= 4 triangles (long own lists only)
+//   CullRec   64 B: single-precision outward-rounded boxes of two children + the two child items
 //   TriShade  80 B per triangle, same order: nc, col, lig, type (touched only on the chosen hit)
 //   SphGeom   32 B: centre, radius;  SphShade 64 B: lig, col, type
 //
@@ -66,8 +66,7 @@ constexpr int LDS_STACK = 24; // traversal-stack levels kept in LDS
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 constexpr unsigned NODE_MASK = 0x0FFFFFFFu;
 constexpr int N_STATS = 7;
-constexpr int CULL_MIN = 12; // own lists longer than this get a culling hierarchy
-constexpr int CULL_LEAF = 4; // triangles per hierarchy leaf
+constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly, longer ones get a hierarchy
 
 // All three kinds of traversal record are 64 bytes with their two integer words last, so a lane
 // fetches "its current record" with one instruction sequence whatever the kind.
@@ -80,20 +79,21 @@ struct __attribute__((aligned(16))) NodeRec { // one kd-tree node (KdTree, kdtre
 static_assert(sizeof(NodeRec) == 64, "NodeRec must be 64 bytes");
 
 struct __attribute__((aligned(16))) CullRec { // one node of a long own list's culling hierarchy
-    double lo[3], hi[3];
+    float lo0[3], hi0[3]; // box of child a, rounded outward to single precision
+    float lo1[3], hi1[3]; // box of child b
+    unsigned a, b;        // child items: another CullRec or one triangle
     double pad;
-    int a, b; // b >= 0: children a, b;  b < 0: leaf with -b triangles starting at TriRec a
 };
 static_assert(sizeof(CullRec) == 64, "CullRec must be 64 bytes");
 
 struct __attribute__((aligned(16))) ListRec { // a node's own list (KdTree::node)
-    double c[3]; // centre of the list's bounding box
-    double k2;   // margin per unit of distance, from the longest triangle edge of the list
-    double r2;   // box half-diagonal + longest edge
-    int first;   // first TriRec of the list
-    int root;    // root CullRec, or -1 when the list is scanned linearly
-    int right;   // the node's right child (0 = none), repeated here for the far-child step
-    int count;   // own-list length
+    double c[3];   // centre of the list's bounding box
+    double k2;     // margin per unit of distance, from the longest triangle edge of the list
+    double r2;     // box half-diagonal + longest edge
+    int first;     // first TriRec of the list
+    unsigned root; // first item of the list's hierarchy (lists longer than SMALL_LIST)
+    int right;     // the node's right child (0 = none), repeated here for the far-child step
+    int count;     // own-list length
     double pad;
 };
 static_assert(sizeof(ListRec) == 64, "ListRec must be 64 bytes");
@@ -190,8 +190,7 @@ __device__ __forceinline__ bool aabb_hit(const double (&mi)[3], const double (&m
 }
 
 // polygon.h:37-60 with E1, E2 precomputed by the same subtractions; returns 1e20 on a miss
-__device__ __forceinline__ double tri_hit(const TriRec &T, d3 o, d3 d) {
-    const d3 p0 = ld3(T.p0), E1 = ld3(T.e1), E2 = ld3(T.e2);
+__device__ __forceinline__ double tri_hit(d3 p0, d3 E1, d3 E2, d3 o, d3 d) {
     const d3 P = cross(d, E2);
     double det = dot(E1, P);
     d3 Tv;
@@ -216,8 +215,9 @@ __device__ __forceinline__ double tri_hit(const TriRec &T, d3 o, d3 d) {
 // and the accepted point lies within 4.4e-10 * L^2 * (|T| + L) of the triangle.  The margin used is
 // (1e-9 * L^2 + 1e-10) * (|o - c| + R + L) with c, R the list box centre / half-diagonal (|T| <=
 // |o - c| + R), i.e. more than twice that bound; the boxes are then inflated by twice the margin
-// again, which also swallows the few-ulp error of the slab arithmetic itself.  The analysis
-// assumes a direction of roughly unit length; other rays take the full scan.
+// again, which also swallows the few-ulp error of the slab arithmetic itself.  The bound is for a
+// unit direction; the rounding errors grow with |d| while the det cut does not, so the margin is
+// multiplied by max(1, |d|).
 __device__ __forceinline__ double list_margin(double cx, double cy, double cz, double k2, double r2, const double (&s)[3]) {
     const double dx = s[0] - cx, dy = s[1] - cy, dz = s[2] - cz;
     return k2 * (sqrt(dx * dx + dy * dy + dz * dz) + r2);
@@ -225,7 +225,7 @@ __device__ __forceinline__ double list_margin(double cx, double cy, double cz, d
 
 // Conservative ray (t >= 0) versus inflated box: never false for a ray the exact triangle test
 // could accept; a false positive only costs an extra exact test.
-__device__ __forceinline__ bool cull_hit(const double (&lo0)[3], const double (&hi0)[3], double m2, const double (&s)[3],
+__device__ __forceinline__ bool slab_hit(const double (&lo0)[3], const double (&hi0)[3], double m2, const double (&s)[3],
                                          const double (&inv)[3], unsigned par) {
     double tmin = 0.0, tmax = 1e300;
     bool ok = true;
@@ -290,15 +290,21 @@ __device__ __forceinline__ void sincos_2pi(double x, double &sn, double &cs) {
 }
 
 // A traversal work item, 32 bits; the per-lane stack holds these.
-//   node item   : node index                                   (enter the node: KdTree::check)
-//   cull item   : IT_CULL | CullRec index                      (one box of a long own list)
-//   after item  : IT_AFTER | flag << 30 | far << 28 | node     (the node's near child is done: own
-//                 list, then the far child; `flag` is the enclosing frame's "has a hit" so far)
-constexpr unsigned IT_CULL = 1u << 30, IT_AFTER = 1u << 31, CULL_MASK = 0x3FFFFFFFu;
-enum { PH_STEP = 0, PH_TRIS = 1, PH_SHADE = 2, PH_DONE = 3 };
+//   node item   : node index (28 bits)                         enter the node: KdTree::check
+//   cull item   : IT_CULL | CullRec index (29 bits)            one record (two boxes) of a list's hierarchy
+//   tri item    : IT_TRI | TriRec index (29 bits)              one exact triangle test
+//   after item  : IT_AFTER | flag << 30 | far << 28 | node     the node's near child is done: own list,
+//                 then the far child; `flag` is the enclosing frame's "has a hit" so far
+constexpr unsigned IT_CULL = 1u << 29, IT_TRI = 2u << 29, IT_AFTER = 1u << 31, IDX29 = 0x1FFFFFFFu;
+enum { K_NODE = 0, K_CULL = 1, K_AFTER = 2, K_TRI = 3, K_SHADE = 4, K_DONE = 5 };
 enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS };
-// slots of the per-lane state kept in HBM (one double each, [slot][thread] so lanes coalesce)
-enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_SLOTS = 12 };
+// slots of the per-lane state kept in HBM (one 8-byte word each, [slot][thread] so lanes coalesce):
+// everything that is only touched between two rays
+enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PIX = 13, LS_SLOTS = 14 };
+
+__device__ __forceinline__ int item_kind(unsigned item) {
+    return (item & IT_AFTER) ? K_AFTER : (int)((item >> 29) & 3) == 0 ? K_NODE : (item & IT_CULL) ? K_CULL : K_TRI;
+}
 
 // The whole path -- camera ray, KdTree::check without recursion, check_node, sphere scan, radiance()
 // as a loop -- runs as ONE loop per wavefront in which every lane is a small state machine, and in
@@ -306,14 +312,14 @@ enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_SLOTS = 12 };
 // for:
 //     node   enter a kd-tree node: check_aabb, choose near / far child          (kdtree.cpp:111-141)
 //     after  a node's near child is finished: start its own list, queue the far child
-//     cull   one box of a long own list's culling hierarchy
-//     tris   a run of <= CULL_MIN exact triangle tests                          (kdtree.cpp:98-109)
+//     cull   one record of a long own list's culling hierarchy (two child boxes)
+//     tri    one exact triangle test                                            (kdtree.cpp:101-107)
 //     shade  sphere scan, material, next ray / next path / next pixel           (raytrace.cpp:41-95,196-205)
 // Lanes that are waiting for another kind simply sit out the iteration, so they pile up until
 // their kind wins the vote; each executed instruction therefore has many active lanes although
-// the 64 rays of a packet diverge completely after the first bounce.  A lane fetches the 64-byte
-// record of its next item as soon as the item is known, so the load is usually complete by the
-// time the lane's kind is scheduled.
+// the 64 rays of a packet diverge completely after the first bounce.  A lane fetches the record
+// of its next item (64 bytes, 80 for a triangle) as soon as the item is known, so the load is
+// usually complete by the time the lane's kind is scheduled.
 //
 // TRACE = false: lanes pull pixels (8x8 blocks, one lane per pixel) from an atomic counter and
 // run each pixel's 4*samps paths in the reference's order.  TRACE = true: lanes pull explicit rays
@@ -339,84 +345,47 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
     auto ls_get3 = [&](int slot) __attribute__((always_inline)) { return mk(ls[slot * lss], ls[(slot + 1) * lss], ls[(slot + 2) * lss]); };
     auto ls_put3 = [&](int slot, d3 a) __attribute__((always_inline)) { ls[slot * lss] = a.x; ls[(slot + 1) * lss] = a.y; ls[(slot + 2) * lss] = a.z; };
 
-    // ---- per-lane state
-    int phase = PH_SHADE;
-    bool have_hit = false;          // a finished traversal is waiting to be shaded
-    // ray
+    // ---- per-lane state held in registers across the loop: the ray, the current item and its
+    // record, the running best, the stack pointer
+    int kind = K_SHADE;
     double s[3] = {0, 0, 0}, v[3] = {0, 0, 1}, inv[3] = {0, 0, 0};
-    unsigned par = 0;
-    bool can_cull = false;
-    // traversal
+    unsigned par = 0; // bit i: direction component i is (nearly) zero
+    float dscale = 1.0f; // max(1, |direction|), rounded up: the culling margin grows with it
     unsigned cur = 0;
-    double rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double rec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int sp = 0;
-    bool flag = false;
+    bool flag = false, have_hit = false;
     double best_t = 1e20, m2 = 0;
-    int best_pos = -1, best_rank = 0, list_first = 0, list_end = 0, tb_first = 0, tb_n = 0;
-    // path / pixel (render mode); throughput, radiance sums and colour sums live in S.lstate
-    unsigned long long rng = 0;
-    int depth = 0, np = 0, sub = 0, smp = 0;
-    unsigned pxy = 0;  // pixel row << 16 | column
-    bool into = true, primary = true;
+    int best_pos = -1, best_rank = 0, list_first = 0, list_end = 0;
+    // path bookkeeping: depth (bits 0-19), pending branches (20-22), sub-pixel (23-24), into (25), primary (26)
+    unsigned pst = 0;
+    int smp = 0;
     unsigned outk = 0; // render: index of the pixel in the packed output; trace: index of the ray
     Pending pend[MAX_SPLIT];
 
     const d3 camo = ld3(cam.o), camd = ld3(cam.d), ccx = ld3(cam.cx), ccy = ld3(cam.cy);
     const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
 
-    auto load_rec = [&](unsigned item) __attribute__((always_inline)) {
-        const char *base = (item & IT_AFTER) ? (const char *)S.lists : (item & IT_CULL) ? (const char *)S.cull : (const char *)S.nodes;
-        const unsigned idx = (item & IT_AFTER) ? (item & NODE_MASK) : (item & CULL_MASK);
-        const double2 *p = (const double2 *)(base + (size_t)idx * 64);
-        const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-        rec[0] = q0.x; rec[1] = q0.y; rec[2] = q1.x; rec[3] = q1.y; rec[4] = q2.x; rec[5] = q2.y; rec[6] = q3.x; rec[7] = q3.y;
-    };
-    auto push = [&](unsigned item) __attribute__((always_inline)) {
-        if (sp < LDS_STACK) stk[sp][tid] = item;
-        else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = item;
-        sp++;
-    };
-    auto pop_next = [&]() __attribute__((always_inline)) {
-        if (sp == 0) phase = PH_SHADE; // the traversal is complete
-        else {
-            sp--;
-            cur = sp < LDS_STACK ? stk[sp][tid] : S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread];
-            load_rec(cur);
-            phase = PH_STEP;
-        }
-    };
-    auto start_traversal = [&](d3 o, d3 d) __attribute__((always_inline)) { // KdTree::check on the root (raytrace.cpp:46)
-        s[0] = o.x; s[1] = o.y; s[2] = o.z; v[0] = d.x; v[1] = d.y; v[2] = d.z;
-        par = (fabs(v[0]) < 1e-150 ? 1u : 0u) | (fabs(v[1]) < 1e-150 ? 2u : 0u) | (fabs(v[2]) < 1e-150 ? 4u : 0u);
-        inv[0] = (par & 1) ? 0.0 : 1.0 / v[0]; inv[1] = (par & 2) ? 0.0 : 1.0 / v[1]; inv[2] = (par & 4) ? 0.0 : 1.0 / v[2];
-        const double dlen2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-        can_cull = dlen2 > 0.25 && dlen2 < 4.0;
-        best_t = 1e20; best_pos = -1; best_rank = 0; list_first = 0; list_end = 0;
-        sp = 0; flag = false;
-        cur = 0;
-        load_rec(cur);
-        phase = PH_STEP;
-        have_hit = true;
-        count(ST_RAYS, 1);
-    };
-
     for (;;) {
-        int kind = -1;
-        if (phase == PH_STEP) kind = (cur & IT_AFTER) ? 2 : (cur & IT_CULL) ? 1 : 0;
-        else if (phase == PH_TRIS) kind = 3;
-        else if (phase == PH_SHADE) kind = 4;
-        const int c0 = __popcll(__ballot(kind == 0)), c1 = __popcll(__ballot(kind == 1)), c2 = __popcll(__ballot(kind == 2)),
-                  c3 = __popcll(__ballot(kind == 3)), c4 = __popcll(__ballot(kind == 4));
-        int pick = 0, most = c0;
-        if (c1 > most) { most = c1; pick = 1; }
-        if (c2 > most) { most = c2; pick = 2; }
-        if (c3 > most) { most = c3; pick = 3; }
-        if (c4 > most) { most = c4; pick = 4; }
+        // ---- vote: run the kind most lanes are waiting for
+        const int c0 = __popcll(__ballot(kind == K_NODE)), c1 = __popcll(__ballot(kind == K_CULL)),
+                  c2 = __popcll(__ballot(kind == K_AFTER)), c3 = __popcll(__ballot(kind == K_TRI)),
+                  c4 = __popcll(__ballot(kind == K_SHADE));
+        int pick = K_NODE, most = c0;
+        if (c1 > most) { most = c1; pick = K_CULL; }
+        if (c2 > most) { most = c2; pick = K_AFTER; }
+        if (c3 > most) { most = c3; pick = K_TRI; }
+        if (c4 > most) { most = c4; pick = K_SHADE; }
         if (most == 0) break; // every lane is done
         pick = __builtin_amdgcn_readfirstlane(pick);
+        const bool run = kind == pick;
+        // what the step leaves behind for the common tail
+        bool want_pop = false;     // fetch the next item from the stack (or finish the traversal)
+        unsigned next = cur;       // otherwise: the item to continue with
+        unsigned push_item = 0;    // item to push before that (0 = none; the root is never pushed)
 
-        if (pick == 0) {
-            if (kind == 0) { // ---- enter a node (kdtree.cpp:111-141)
+        if (pick == K_NODE) {
+            if (run) { // ---- enter a node (kdtree.cpp:111-141)
                 const double mi[3] = {rec[0], rec[1], rec[2]}, ma[3] = {rec[3], rec[4], rec[5]};
                 const double split = rec[6];
                 const long long w7 = __double_as_longlong(rec[7]);
@@ -424,7 +393,11 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                 const unsigned info = (unsigned)(w7 >> 32);
                 const int node = (int)cur;
                 count(ST_VISITS, 1);
-                if (!aabb_hit(mi, ma, s, v)) pop_next();
+                // cheap necessary condition first: check_aabb can only accept a ray that meets the
+                // box grown by eps (plus rounding); clear misses skip the three divisions
+                const double pad = 2.5e-5 + 4e-12 * (fabs(s[0]) + fabs(s[1]) + fabs(s[2]) + fabs(mi[0]) + fabs(mi[1]) + fabs(mi[2]) +
+                                                    fabs(ma[0]) + fabs(ma[1]) + fabs(ma[2]));
+                if (!slab_hit(mi, ma, pad, s, inv, par) || !aabb_hit(mi, ma, s, v)) want_pop = true;
                 else {
                     const int axis = info & 3;
                     const bool hasL = (info >> 2) & 1, hasR = right > 0;
@@ -447,65 +420,84 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                     // travels in the item and the near subtree starts with a clean one
                     const unsigned after = IT_AFTER | ((unsigned)flag << 30) | (farkind << 28) | (unsigned)node;
                     flag = false;
-                    if (near >= 0) { push(after); cur = (unsigned)near; }
-                    else cur = after;
-                    load_rec(cur);
+                    if (near >= 0) { push_item = after; next = (unsigned)near; }
+                    else next = after;
                 }
             }
-        } else if (pick == 1) {
-            if (kind == 1) { // ---- one culling box of a long own list
-                const double lo[3] = {rec[0], rec[1], rec[2]}, hi[3] = {rec[3], rec[4], rec[5]};
-                const long long w7 = __double_as_longlong(rec[7]);
-                const int a = (int)w7, b = (int)(w7 >> 32);
+        } else if (pick == K_CULL) {
+            if (run) { // ---- one record of a long own list's hierarchy: the boxes of its two children
                 count(ST_CULLS, 1);
-                if (!cull_hit(lo, hi, m2, s, inv, par)) pop_next();
-                else if (b < 0) { tb_first = a; tb_n = -b; phase = PH_TRIS; }
-                else { push(IT_CULL | (unsigned)b); cur = IT_CULL | (unsigned)a; load_rec(cur); }
+                const float2 f0 = __builtin_bit_cast(float2, rec[0]), f1 = __builtin_bit_cast(float2, rec[1]),
+                             f2 = __builtin_bit_cast(float2, rec[2]), f3 = __builtin_bit_cast(float2, rec[3]),
+                             f4 = __builtin_bit_cast(float2, rec[4]), f5 = __builtin_bit_cast(float2, rec[5]);
+                const double lo0[3] = {f0.x, f0.y, f1.x}, hi0[3] = {f1.y, f2.x, f2.y};
+                const double lo1[3] = {f3.x, f3.y, f4.x}, hi1[3] = {f4.y, f5.x, f5.y};
+                const long long w6 = __double_as_longlong(rec[6]);
+                const unsigned a = (unsigned)w6, b = (unsigned)(w6 >> 32);
+                const bool h0 = slab_hit(lo0, hi0, m2, s, inv, par), h1 = slab_hit(lo1, hi1, m2, s, inv, par);
+                if (h0 && h1) { push_item = b; next = a; }
+                else if (h0) next = a;
+                else if (h1) next = b;
+                else want_pop = true;
             }
-        } else if (pick == 2) {
-            if (kind == 2) { // ---- near child finished: own list (kdtree.cpp:122,131,137), then far child
+        } else if (pick == K_AFTER) {
+            if (run) { // ---- near child finished: own list (kdtree.cpp:122,131,137), then far child
                 const int node = (int)(cur & NODE_MASK);
                 const unsigned farkind = (cur >> 28) & 3;
                 const bool near_hit = flag;            // what the near child's check() returned
                 flag = ((cur >> 30) & 1) | near_hit;   // back in the enclosing frame
                 const long long w5 = __double_as_longlong(rec[5]), w6 = __double_as_longlong(rec[6]);
-                const int first = (int)w5, root = (int)(w5 >> 32), right = (int)w6, count_ = (int)(w6 >> 32);
+                const int first = (int)w5, right = (int)w6, count_ = (int)(w6 >> 32);
+                const unsigned root = (unsigned)(w5 >> 32); // first item of the list's hierarchy
                 count(ST_TRIS, (unsigned)count_);
-                if (farkind != 0 && !near_hit) push(farkind == 1 ? (unsigned)(node + 1) : (unsigned)right); // kdtree.cpp:124,133
-                if (count_ == 0) pop_next();
+                if (farkind != 0 && !near_hit) { // kdtree.cpp:124,133: the far child comes after the list
+                    const unsigned far = farkind == 1 ? (unsigned)(node + 1) : (unsigned)right;
+                    if (sp < LDS_STACK) stk[sp][tid] = far;
+                    else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = far;
+                    sp++;
+                }
+                if (count_ == 0) want_pop = true;
                 else {
                     list_first = first; list_end = first + count_;
-                    if (root < 0 || !can_cull) { tb_first = first; tb_n = count_; phase = PH_TRIS; }
-                    else {
-                        m2 = 2.0 * list_margin(rec[0], rec[1], rec[2], rec[3], rec[4], s);
-                        cur = IT_CULL | (unsigned)root;
-                        load_rec(cur);
+                    if (count_ <= SMALL_LIST) { // every triangle, in list order
+                        for (int i = count_ - 1; i > 0; i--) {
+                            const unsigned it = IT_TRI | (unsigned)(first + i);
+                            if (sp < LDS_STACK) stk[sp][tid] = it;
+                            else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = it;
+                            sp++;
+                        }
+                        next = IT_TRI | (unsigned)first;
+                    } else {
+                        m2 = 2.0 * (double)dscale * list_margin(rec[0], rec[1], rec[2], rec[3], rec[4], s);
+                        next = root;
                     }
                 }
             }
-        } else if (pick == 3) {
-            if (kind == 3) { // ---- exact triangle tests (kdtree.cpp:101-107)
+        } else if (pick == K_TRI) {
+            if (run) { // ---- one exact triangle test (kdtree.cpp:105)
                 const d3 o = mk(s[0], s[1], s[2]), d = mk(v[0], v[1], v[2]);
-                for (int i = 0; i < tb_n; i++) {
-                    const TriRec &T = S.tris[tb_first + i];
-                    const double t = tri_hit(T, o, d);
-                    if (t > EPS) {
-                        const int rk = T.rank;
-                        // strict < keeps the earlier of two equal distances; inside one list "earlier"
-                        // is the lower rank, across lists it is the list visited first
-                        if (t < best_t || (t == best_t && best_pos >= list_first && best_pos < list_end && rk < best_rank)) {
-                            best_t = t; best_pos = tb_first + i; best_rank = rk;
-                        }
-                        if (t < 1e10) flag = true;
+                const double t = tri_hit(mk(rec[0], rec[1], rec[2]), mk(rec[3], rec[4], rec[5]), mk(rec[6], rec[7], rec[8]), o, d);
+                count(ST_DONE, 1);
+                if (t > EPS) {
+                    const int pos = (int)(cur & IDX29);
+                    const int rk = (int)(__double_as_longlong(rec[9]) >> 32);
+                    // strict < keeps the earlier of two equal distances; inside one list "earlier"
+                    // is the lower rank, across lists it is the list visited first
+                    if (t < best_t || (t == best_t && best_pos >= list_first && best_pos < list_end && rk < best_rank)) {
+                        best_t = t; best_pos = pos; best_rank = rk;
                     }
+                    if (t < 1e10) flag = true;
                 }
-                count(ST_DONE, (unsigned)tb_n);
-                pop_next();
+                want_pop = true;
             }
         } else {
-            if (kind == 4) { // ---- traversal finished (or nothing started yet)
+            if (run) { // ---- traversal finished (or nothing started yet)
                 bool go_on = false, need_primary = false, need_work = false;
                 d3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+                int depth = (int)(pst & 0xFFFFF), np = (int)((pst >> 20) & 7), sub = (int)((pst >> 23) & 3);
+                bool into = (pst >> 25) & 1, primary = (pst >> 26) & 1;
+                unsigned long long rng = 0;
+                if (!TRACE) rng = (unsigned long long)__double_as_longlong(ls[LS_RNG * lss]);
                 if (have_hit) {
                     have_hit = false;
                     const d3 o = mk(s[0], s[1], s[2]), d = mk(v[0], v[1], v[2]);
@@ -601,6 +593,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                                 const d3 col = ls_get3(LS_COL) + mk(clamp01(rsum.x), clamp01(rsum.y), clamp01(rsum.z)) * .25;
                                 rsum = mk(0, 0, 0);
                                 if (++sub == 4) {
+                                    sub = 0;
                                     rgb[3 * (size_t)outk] = col.x; rgb[3 * (size_t)outk + 1] = col.y; rgb[3 * (size_t)outk + 2] = col.z;
                                     need_work = true;
                                 } else ls_put3(LS_COL, col);
@@ -612,6 +605,8 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                 } else need_work = true; // first iteration: nothing traced yet
 
                 // ---- lanes without work take the next pixel (or ray) from the shared counter
+                unsigned pxy = 0;
+                if (!TRACE && need_primary) pxy = (unsigned)__double_as_longlong(ls[LS_PIX * lss]);
                 for (;;) {
                     const unsigned long long want = __ballot(need_work);
                     if (want == 0) break;
@@ -621,7 +616,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                     base = __shfl(base, leader, 64);
                     if (need_work) {
                         const unsigned w = base + (unsigned)__popcll(want & lane_lt);
-                        if (w >= n_work) { need_work = false; phase = PH_DONE; }
+                        if (w >= n_work) { need_work = false; kind = K_DONE; }
                         else if (TRACE) { outk = w; need_work = false; go_on = true; ro = ld3(rays + 6 * (size_t)w); rd = ld3(rays + 6 * (size_t)w + 3); }
                         else {
                             const unsigned blk = w >> 6, li = w & 63;
@@ -635,6 +630,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                             const int lrow = (b / T.blk_cols) * 8 + (int)(li >> 3), lcol = (b % T.blk_cols) * 8 + (int)(li & 7);
                             if (lrow < T.rows && lcol < T.cols) { // ragged edge blocks have unused lanes
                                 pxy = ((unsigned)(T.x0 + lrow) << 16) | (unsigned)(T.y0 + lcol);
+                                ls[LS_PIX * lss] = __longlong_as_double((long long)pxy);
                                 outk = (unsigned)(T.out_off + (long long)lrow * T.cols + lcol);
                                 sub = 0; smp = 0;
                                 ls_put3(LS_COL, mk(0, 0, 0)); ls_put3(LS_RSUM, mk(0, 0, 0));
@@ -664,7 +660,49 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                     depth = 0; into = true; np = 0; primary = true;
                     go_on = true;
                 }
-                if (go_on) start_traversal(ro, rd);
+                if (!TRACE) ls[LS_RNG * lss] = __longlong_as_double((long long)rng);
+                pst = (unsigned)depth | ((unsigned)np << 20) | ((unsigned)sub << 23) | ((unsigned)into << 25) | ((unsigned)primary << 26);
+                if (go_on) { // KdTree::check on the root (raytrace.cpp:46)
+                    s[0] = ro.x; s[1] = ro.y; s[2] = ro.z; v[0] = rd.x; v[1] = rd.y; v[2] = rd.z;
+                    par = (fabs(v[0]) < 1e-150 ? 1u : 0u) | (fabs(v[1]) < 1e-150 ? 2u : 0u) | (fabs(v[2]) < 1e-150 ? 4u : 0u);
+                    inv[0] = (par & 1) ? 0.0 : 1.0 / v[0]; inv[1] = (par & 2) ? 0.0 : 1.0 / v[1]; inv[2] = (par & 4) ? 0.0 : 1.0 / v[2];
+                    const float dl = (float)sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * 1.000001f;
+                    dscale = dl > 1.0f ? dl : 1.0f;
+                    best_t = 1e20; best_pos = -1; best_rank = 0; list_first = 0; list_end = 0;
+                    sp = 0; flag = false;
+                    have_hit = true;
+                    count(ST_RAYS, 1);
+                    next = 0; // the root node
+                }
+            }
+        }
+
+        // ---- common tail for the lanes that ran: push, pop, fetch the next item's record
+        if (run && kind != K_DONE) {
+            bool fetch = true;
+            if (pick == K_SHADE) fetch = have_hit; // a new traversal starts at the root, otherwise the lane is done or idle
+            if (push_item != 0) {
+                if (sp < LDS_STACK) stk[sp][tid] = push_item;
+                else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = push_item;
+                sp++;
+            }
+            if (want_pop) {
+                if (sp == 0) { kind = K_SHADE; fetch = false; } // the traversal is complete
+                else {
+                    sp--;
+                    next = sp < LDS_STACK ? stk[sp][tid] : S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread];
+                }
+            }
+            if (fetch) {
+                cur = next;
+                kind = item_kind(cur);
+                const char *base = kind == K_NODE ? (const char *)S.nodes : kind == K_CULL ? (const char *)S.cull
+                                   : kind == K_AFTER ? (const char *)S.lists : (const char *)S.tris;
+                const unsigned idx = kind == K_AFTER ? (cur & NODE_MASK) : (cur & IDX29);
+                const double2 *p = (const double2 *)(base + (size_t)idx * (kind == K_TRI ? 80u : 64u));
+                const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                rec[0] = q0.x; rec[1] = q0.y; rec[2] = q1.x; rec[3] = q1.y; rec[4] = q2.x; rec[5] = q2.y; rec[6] = q3.x; rec[7] = q3.y;
+                if (kind == K_TRI) { const double2 q4 = p[4]; rec[8] = q4.x; rec[9] = q4.y; }
             }
         }
     }
@@ -726,28 +764,28 @@ struct rt_scene {
 namespace {
 
 // Culling hierarchy for one long own list: median splits of the triangle centroids along the
-// widest axis down to CULL_LEAF triangles.  `order[first..first+count)` is permuted into leaf
-// order; boxes are the exact (uninflated) bounds of the triangles below.
+// widest axis down to single triangles.  A CullRec holds the boxes of its two children (exact
+// bounds rounded OUTWARD to single precision) and the children as work items, so one 64-byte fetch
+// decides both subtrees and a triangle is only fetched when its own box is met.
+// `order[first..first+count)` is permuted into the hierarchy's left-to-right leaf order.
 struct CullTri { double lo[3], hi[3], c[3]; int src; };
 
-int cull_rec(std::vector<CullRec> &out, std::vector<CullTri> &bt, int a, int b, int first, int depth, int &max_depth) {
-    const int me = (int)out.size();
-    out.emplace_back();
+float f_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; }
+float f_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; }
+
+// returns the work item for the range [a, b) and its exact bounds in lo/hi
+unsigned cull_rec(std::vector<CullRec> &out, std::vector<CullTri> &bt, int a, int b, int first, int depth, int &max_depth,
+                  double lo[3], double hi[3]) {
     if (depth > max_depth) max_depth = depth;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    if (b - a == 1) {
+        for (int k = 0; k < 3; k++) { lo[k] = bt[a].lo[k]; hi[k] = bt[a].hi[k]; }
+        return IT_TRI | (unsigned)(first + a);
+    }
+    const size_t me = out.size();
+    out.emplace_back();
     double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
     for (int i = a; i < b; i++)
-        for (int k = 0; k < 3; k++) {
-            lo[k] = std::min(lo[k], bt[i].lo[k]); hi[k] = std::max(hi[k], bt[i].hi[k]);
-            clo[k] = std::min(clo[k], bt[i].c[k]); chi[k] = std::max(chi[k], bt[i].c[k]);
-        }
-    for (int k = 0; k < 3; k++) { out[me].lo[k] = lo[k]; out[me].hi[k] = hi[k]; }
-    out[me].pad = 0;
-    if (b - a <= CULL_LEAF) {
-        out[me].a = first + a;
-        out[me].b = -(b - a);
-        return me;
-    }
+        for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], bt[i].c[k]); chi[k] = std::max(chi[k], bt[i].c[k]); }
     int ax = 0;
     if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
     if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
@@ -755,11 +793,17 @@ int cull_rec(std::vector<CullRec> &out, std::vector<CullTri> &bt, int a, int b, 
     std::nth_element(bt.begin() + a, bt.begin() + mid, bt.begin() + b, [ax](const CullTri &x, const CullTri &y) {
         return x.c[ax] < y.c[ax] || (x.c[ax] == y.c[ax] && x.src < y.src);
     });
-    const int l = cull_rec(out, bt, a, mid, first, depth + 1, max_depth);
-    const int r = cull_rec(out, bt, mid, b, first, depth + 1, max_depth);
-    out[me].a = l;
-    out[me].b = r;
-    return me;
+    double l0[3], h0[3], l1[3], h1[3];
+    const unsigned ia = cull_rec(out, bt, a, mid, first, depth + 1, max_depth, l0, h0);
+    const unsigned ib = cull_rec(out, bt, mid, b, first, depth + 1, max_depth, l1, h1);
+    CullRec &r = out[me];
+    for (int k = 0; k < 3; k++) {
+        r.lo0[k] = f_down(l0[k]); r.hi0[k] = f_up(h0[k]);
+        r.lo1[k] = f_down(l1[k]); r.hi1[k] = f_up(h1[k]);
+        lo[k] = std::min(l0[k], l1[k]); hi[k] = std::max(h0[k], h1[k]);
+    }
+    r.a = ia; r.b = ib; r.pad = 0;
+    return IT_CULL | (unsigned)me;
 }
 
 void build_cull(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<CullRec> &cull, ListRec &li,
@@ -782,14 +826,14 @@ void build_cull(const rt_scene_desc *D, int first, int count, std::vector<int> &
         }
     }
     int depth = 0;
-    li.root = cull_rec(cull, bt, 0, count, first, 1, depth);
+    double lo[3], hi[3];
+    li.root = cull_rec(cull, bt, 0, count, first, 1, depth, lo, hi);
     max_depth = std::max(max_depth, depth);
     for (int j = 0; j < count; j++) order[first + j] = bt[j].src;
-    const CullRec &root = cull[li.root];
     double r2 = 0;
     for (int k = 0; k < 3; k++) {
-        li.c[k] = 0.5 * (root.lo[k] + root.hi[k]);
-        r2 += 0.25 * (root.hi[k] - root.lo[k]) * (root.hi[k] - root.lo[k]);
+        li.c[k] = 0.5 * (lo[k] + hi[k]);
+        r2 += 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]);
     }
     li.k2 = 1e-9 * lmax2 + 1e-10;         // see list_margin()
     li.r2 = std::sqrt(r2) + std::sqrt(lmax2);
@@ -970,13 +1014,13 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         n.info = (unsigned)D->node_axis[i] | (D->node_left[i] >= 0 ? 4u : 0u);
         ListRec &li = lists[i];
         li.first = D->node_first[i];
-        li.root = -1;
+        li.root = 0;
         li.right = n.right;
         li.count = D->node_count[i];
         li.c[0] = li.c[1] = li.c[2] = 0; li.k2 = 0; li.r2 = 0; li.pad = 0;
-        if (D->node_count[i] > CULL_MIN) build_cull(D, D->node_first[i], D->node_count[i], order, cull, li, cull_depth);
+        if (D->node_count[i] > SMALL_LIST) build_cull(D, D->node_first[i], D->node_count[i], order, cull, li, cull_depth);
     }
-    if (cull.size() > 0x7FFFFFF0ull) return fail(RT_E_LIMIT, "culling hierarchy too large");
+    if (cull.size() > (size_t)IDX29 || (unsigned)D->n_tris > IDX29) return fail(RT_E_LIMIT, "scene too large for 29-bit item indices");
     std::vector<TriRec> tris((size_t)D->n_tris);
     std::vector<TriShade> tsh((size_t)D->n_tris);
     for (int pos = 0; pos < D->n_list; pos++) {
@@ -1031,7 +1075,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         per_cu = 2;
     s->grid = pr.multiProcessorCount * per_cu;
     const int n_threads = s->grid * BLOCK;
-    const int need_depth = D->tree_depth + cull_depth + 2; // main frames plus one list's culling walk on top
+    const int need_depth = D->tree_depth + cull_depth + SMALL_LIST + 2; // main frames plus one list's culling walk on top
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK : 0;
     hipError_t e = hipSuccess;
     if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_threads * sizeof(unsigned));
