@@ -186,9 +186,11 @@ def main():
                                      "tri_tests_done": per_launch["tri_tests_done"] / max(1, per_launch["rays"]),
                                      "cull_tests": per_launch["cull_tests"] / max(1, per_launch["rays"]),
                                      "sph_tests": per_launch["sph_tests"] / max(1, per_launch["rays"]),
+                                     "sched_steps_x64": 64 * per_launch["sched_steps"] / max(1, per_launch["rays"]),
                                      "alg_bytes": alg_bytes / max(1, per_launch["rays"]),
                                      "reference_bytes": ref_bytes / max(1, per_launch["rays"])},
                          "reference_work_GBps": ref_bytes / (avg_ms * 1e-3) / 1e9,
+                         "active_lane_fraction_per_step": per_launch["sched_lanes"] / max(1, 64 * per_launch["sched_steps"]),
                          "fp64_valu": {"achieved_tflops": alg_flops / (avg_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                                        "frac": alg_flops / (avg_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}},
         }

@@ -120,7 +120,11 @@ typedef struct rt_stats {
     uint64_t tri_shades;  /* rays whose chosen hit is a triangle (raytrace.cpp:58-67) */
     /* what the kernel actually executed (long own lists are culled conservatively, results unchanged) */
     uint64_t tri_tests_done; /* exact triangle tests performed */
-    uint64_t cull_tests;     /* culling-box tests performed */
+    uint64_t cull_tests;     /* culling records (two boxes each) tested */
+    /* the wavefront scheduler: steps executed and lanes that took part in them
+     * (sched_lanes / (64 * sched_steps) = fraction of lanes doing useful work per step) */
+    uint64_t sched_steps;
+    uint64_t sched_lanes;
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* opaque, one per (scene, device) */

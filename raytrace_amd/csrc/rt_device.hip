@@ -64,50 +64,53 @@ constexpr double EPS = 1e-5;  // point.h:7
 constexpr int BLOCK = 256;    // threads per workgroup (4 wavefronts)
 constexpr int LDS_STACK = 24; // traversal-stack levels kept in LDS
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
-constexpr unsigned NODE_MASK = 0x0FFFFFFFu;
-constexpr int N_STATS = 7;
+constexpr int N_STATS = 9;
 constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly, longer ones get a hierarchy
 
-// All three kinds of traversal record are 64 bytes with their two integer words last, so a lane
-// fetches "its current record" with one instruction sequence whatever the kind.
+// Every traversal record lives in ONE pool addressed in 16-byte granules, and a work item carries
+// the granule of its record, so a lane fetches "the record of my next item" with the same five
+// 16-byte loads whatever the item is:
+//   node i        granule 8*i      NodeRec (64 B) followed by its ListRec (64 B)
+//   cull record   4 granules       CullRec (64 B)
+//   triangle      5 granules       TriRec (80 B)
 struct __attribute__((aligned(16))) NodeRec { // one kd-tree node (KdTree, kdtree.h:96-116)
     double mi[3], ma[3];
     double split;
-    int right;     // 0 = none (the root is never a child)
-    unsigned info; // bits 0-1 axis, bit 2 has-left
+    unsigned right; // granule of the right child, 0 = none (the root is never a child)
+    unsigned info;  // bits 0-1 axis, bit 2 has-left, bits 3.. own-list length
 };
 static_assert(sizeof(NodeRec) == 64, "NodeRec must be 64 bytes");
 
-struct __attribute__((aligned(16))) CullRec { // one node of a long own list's culling hierarchy
-    float lo0[3], hi0[3]; // box of child a, rounded outward to single precision
-    float lo1[3], hi1[3]; // box of child b
-    unsigned a, b;        // child items: another CullRec or one triangle
+// Boxes of two children (exact bounds rounded OUTWARD to single precision) and the children as
+// work items.  A CullRec is an inner node of a long own list's culling hierarchy; a ListRec is the
+// hierarchy's root merged with what the node's "near child finished" step needs.
+struct __attribute__((aligned(16))) CullRec {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    unsigned a, b;
     double pad;
 };
 static_assert(sizeof(CullRec) == 64, "CullRec must be 64 bytes");
 
 struct __attribute__((aligned(16))) ListRec { // a node's own list (KdTree::node)
-    double c[3];   // centre of the list's bounding box
-    double k2;     // margin per unit of distance, from the longest triangle edge of the list
-    double r2;     // box half-diagonal + longest edge
-    int first;     // first TriRec of the list
-    unsigned root; // first item of the list's hierarchy (lists longer than SMALL_LIST)
-    int right;     // the node's right child (0 = none), repeated here for the far-child step
-    int count;     // own-list length
-    double pad;
+    float lo0[3], hi0[3], lo1[3], hi1[3]; // long lists only
+    unsigned a, b;  // long list: the two child items; short list: a = item of the first triangle
+    unsigned right; // granule of the node's right child (0 = none), for the far-child step
+    unsigned meta;  // long list: bits of (float) squared longest triangle edge; short: LIST_SHORT | length
 };
 static_assert(sizeof(ListRec) == 64, "ListRec must be 64 bytes");
+constexpr unsigned LIST_SHORT = 0x80000000u;
 
 struct __attribute__((aligned(16))) TriRec {
     double p0[3], e1[3], e2[3];
-    int gid;  // global triangle id
+    int pos;  // index of the triangle's TriShade
     int rank; // position in the reference's list order (decides between equal distances)
 };
 static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
 
 struct __attribute__((aligned(16))) TriShade {
     double nc[3], col[3], lig[3];
-    int type, pad;
+    int type;
+    int gid; // global triangle id
 };
 static_assert(sizeof(TriShade) == 80, "TriShade must be 80 bytes");
 
@@ -116,16 +119,13 @@ struct __attribute__((aligned(16))) SphShade { double lig[3], col[3]; int type, 
 static_assert(sizeof(SphShade) == 64, "SphShade must be 64 bytes");
 
 struct DevScene {
-    const NodeRec *nodes;
-    const ListRec *lists;
-    const CullRec *cull;
-    const TriRec *tris;
+    const char *pool; // nodes + lists, cull records, triangles
     const TriShade *tshade;
     const SphGeom *sph;
     const SphShade *sshade;
-    unsigned *ovf; // overflow stack [ovf_depth][n_threads]
+    unsigned *ovf;  // overflow stack [ovf_depth][n_threads]
     double *lstate; // per-lane path state that is only touched between rays [LS_SLOTS][n_threads]
-    int n_nodes, n_tris, n_sph;
+    int n_sph;
     int ovf_depth;
     int n_threads;
 };
@@ -168,25 +168,27 @@ __host__ __device__ __forceinline__ unsigned long long path_state(unsigned long 
     return z >> 16;
 }
 
-// kdtree.h:57-76
+// kdtree.h:57-76.  The three axes are tried one after the other, each behind a branch, exactly as
+// the reference's loop returns at the first axis that accepts: later divisions are skipped and the
+// temporaries of one axis are dead before the next starts.
 __device__ __forceinline__ bool aabb_hit(const double (&mi)[3], const double (&ma)[3], const double (&s)[3],
                                          const double (&v)[3]) {
     if (mi[0] < s[0] + EPS && s[0] < ma[0] + EPS && mi[1] < s[1] + EPS && s[1] < ma[1] + EPS && mi[2] < s[2] + EPS &&
         s[2] < ma[2] + EPS)
         return true;
-    bool hit = false;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int j = (i + 1) % 3, k = (i + 2) % 3;
-        if (fabs(v[i]) > EPS) {
-            const double t = ((v[i] > 0 ? mi[i] : ma[i]) - s[i]) / v[i];
-            if (t > EPS) {
-                const double pj = s[j] + v[j] * t, pk = s[k] + v[k] * t;
-                if (mi[j] < pj + EPS && pj < ma[j] + EPS && mi[k] < pk + EPS && pk < ma[k] + EPS) hit = true;
-            }
-        }
+#define RT_AABB_AXIS(i, j, k)                                                                                   \
+    if (fabs(v[i]) > EPS) {                                                                                     \
+        const double t = ((v[i] > 0 ? mi[i] : ma[i]) - s[i]) / v[i];                                            \
+        if (t > EPS) {                                                                                          \
+            const double pj = s[j] + v[j] * t, pk = s[k] + v[k] * t;                                            \
+            if (mi[j] < pj + EPS && pj < ma[j] + EPS && mi[k] < pk + EPS && pk < ma[k] + EPS) return true;      \
+        }                                                                                                       \
     }
-    return hit;
+    RT_AABB_AXIS(0, 1, 2)
+    RT_AABB_AXIS(1, 2, 0)
+    RT_AABB_AXIS(2, 0, 1)
+#undef RT_AABB_AXIS
+    return false;
 }
 
 // polygon.h:37-60 with E1, E2 precomputed by the same subtractions; returns 1e20 on a miss
@@ -289,37 +291,35 @@ __device__ __forceinline__ void sincos_2pi(double x, double &sn, double &cs) {
     cs = q == 0 ? kc : q == 1 ? -ks : q == 2 ? -kc : ks;
 }
 
-// A traversal work item, 32 bits; the per-lane stack holds these.
-//   node item   : node index (28 bits)                         enter the node: KdTree::check
-//   cull item   : IT_CULL | CullRec index (29 bits)            one record (two boxes) of a list's hierarchy
-//   tri item    : IT_TRI | TriRec index (29 bits)              one exact triangle test
-//   after item  : IT_AFTER | flag << 30 | far << 28 | node     the node's near child is done: own list,
-//                 then the far child; `flag` is the enclosing frame's "has a hit" so far
-constexpr unsigned IT_CULL = 1u << 29, IT_TRI = 2u << 29, IT_AFTER = 1u << 31, IDX29 = 0x1FFFFFFFu;
-enum { K_NODE = 0, K_CULL = 1, K_AFTER = 2, K_TRI = 3, K_SHADE = 4, K_DONE = 5 };
-enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS };
+// A traversal work item, 32 bits; the per-lane stack holds these.  The low bits are the granule
+// of the item's record in the pool.
+//   node item   : granule (29 bits), kind bits 00            enter the node: KdTree::check
+//   cull item   : IT_CULL | granule                          one inner record of a list's hierarchy
+//   tri item    : IT_TRI | granule                           one exact triangle test
+//   after item  : IT_AFTER | flag << 30 | far << 28 | node granule (28 bits)
+//                 the node's near child is done: own list, then the far child; `flag` is the
+//                 enclosing frame's "has a hit" so far.  Its record is the node's ListRec.
+constexpr unsigned IT_CULL = 1u << 29, IT_TRI = 2u << 29, IT_AFTER = 1u << 31, IDX29 = 0x1FFFFFFFu, IDX28 = 0x0FFFFFFFu;
+enum { K_NODE = 0, K_CULL = 1, K_TRI = 2, K_SHADE = 3, K_DONE = 4 };
+enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, ST_ITERS, ST_LANES };
 // slots of the per-lane state kept in HBM (one 8-byte word each, [slot][thread] so lanes coalesce):
 // everything that is only touched between two rays
 enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PIX = 13, LS_SLOTS = 14 };
-
-__device__ __forceinline__ int item_kind(unsigned item) {
-    return (item & IT_AFTER) ? K_AFTER : (int)((item >> 29) & 3) == 0 ? K_NODE : (item & IT_CULL) ? K_CULL : K_TRI;
-}
 
 // The whole path -- camera ray, KdTree::check without recursion, check_node, sphere scan, radiance()
 // as a loop -- runs as ONE loop per wavefront in which every lane is a small state machine, and in
 // every iteration the wavefront executes the one kind of work that most of its lanes are waiting
 // for:
 //     node   enter a kd-tree node: check_aabb, choose near / far child          (kdtree.cpp:111-141)
-//     after  a node's near child is finished: start its own list, queue the far child
-//     cull   one record of a long own list's culling hierarchy (two child boxes)
+//     cull   two child boxes of a long own list's culling hierarchy; the first such step of a list
+//            also does the bookkeeping of "the node's near child has returned"   (kdtree.cpp:122-125)
 //     tri    one exact triangle test                                            (kdtree.cpp:101-107)
 //     shade  sphere scan, material, next ray / next path / next pixel           (raytrace.cpp:41-95,196-205)
 // Lanes that are waiting for another kind simply sit out the iteration, so they pile up until
 // their kind wins the vote; each executed instruction therefore has many active lanes although
 // the 64 rays of a packet diverge completely after the first bounce.  A lane fetches the record
-// of its next item (64 bytes, 80 for a triangle) as soon as the item is known, so the load is
-// usually complete by the time the lane's kind is scheduled.
+// of its next item as soon as the item is known, so the load is usually complete by the time the
+// lane's kind is scheduled.
 //
 // TRACE = false: lanes pull pixels (8x8 blocks, one lane per pixel) from an atomic counter and
 // run each pixel's 4*samps paths in the reference's order.  TRACE = true: lanes pull explicit rays
@@ -340,6 +340,11 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
     auto count = [&](int k, unsigned n) __attribute__((always_inline)) {
         __hip_atomic_fetch_add(&sacc[k][tid], (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
+    auto push = [&](int &sp_, unsigned item) __attribute__((always_inline)) {
+        if (sp_ < LDS_STACK) stk[sp_][tid] = item;
+        else S.ovf[(size_t)(sp_ - LDS_STACK) * S.n_threads + gthread] = item;
+        sp_++;
+    };
     double *const ls = S.lstate + gthread;
     const size_t lss = (size_t)S.n_threads;
     auto ls_get3 = [&](int slot) __attribute__((always_inline)) { return mk(ls[slot * lss], ls[(slot + 1) * lss], ls[(slot + 2) * lss]); };
@@ -349,14 +354,14 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
     // record, the running best, the stack pointer
     int kind = K_SHADE;
     double s[3] = {0, 0, 0}, v[3] = {0, 0, 1}, inv[3] = {0, 0, 0};
-    unsigned par = 0; // bit i: direction component i is (nearly) zero
+    unsigned par = 0;    // bit i: direction component i is (nearly) zero
     float dscale = 1.0f; // max(1, |direction|), rounded up: the culling margin grows with it
     unsigned cur = 0;
     double rec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int sp = 0;
     bool flag = false, have_hit = false;
     double best_t = 1e20, m2 = 0;
-    int best_pos = -1, best_rank = 0, list_first = 0, list_end = 0;
+    int best_pos = -1, best_rank = 0, best_list = -1, cur_list = -1;
     // path bookkeeping: depth (bits 0-19), pending branches (20-22), sub-pixel (23-24), into (25), primary (26)
     unsigned pst = 0;
     int smp = 0;
@@ -368,30 +373,28 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
 
     for (;;) {
         // ---- vote: run the kind most lanes are waiting for
-        const int c0 = __popcll(__ballot(kind == K_NODE)), c1 = __popcll(__ballot(kind == K_CULL)),
-                  c2 = __popcll(__ballot(kind == K_AFTER)), c3 = __popcll(__ballot(kind == K_TRI)),
-                  c4 = __popcll(__ballot(kind == K_SHADE));
+        const int c0 = (int)__builtin_popcountll(__ballot(kind == K_NODE)), c1 = (int)__builtin_popcountll(__ballot(kind == K_CULL)),
+                  c2 = (int)__builtin_popcountll(__ballot(kind == K_TRI)), c3 = (int)__builtin_popcountll(__ballot(kind == K_SHADE));
         int pick = K_NODE, most = c0;
         if (c1 > most) { most = c1; pick = K_CULL; }
-        if (c2 > most) { most = c2; pick = K_AFTER; }
-        if (c3 > most) { most = c3; pick = K_TRI; }
-        if (c4 > most) { most = c4; pick = K_SHADE; }
+        if (c2 > most) { most = c2; pick = K_TRI; }
+        if (c3 > most) { most = c3; pick = K_SHADE; }
         if (most == 0) break; // every lane is done
         pick = __builtin_amdgcn_readfirstlane(pick);
         const bool run = kind == pick;
+        if (lane == 0) { count(ST_ITERS, 1); count(ST_LANES, (unsigned)most); } // scheduler statistics, one lane per wavefront
         // what the step leaves behind for the common tail
-        bool want_pop = false;     // fetch the next item from the stack (or finish the traversal)
-        unsigned next = cur;       // otherwise: the item to continue with
-        unsigned push_item = 0;    // item to push before that (0 = none; the root is never pushed)
+        bool want_pop = false;  // take the next item from the stack (or finish the traversal)
+        unsigned next = 0;      // otherwise: the item to continue with
+        unsigned push_item = 0; // item to push before that (0 = none; the root is never pushed)
 
         if (pick == K_NODE) {
             if (run) { // ---- enter a node (kdtree.cpp:111-141)
                 const double mi[3] = {rec[0], rec[1], rec[2]}, ma[3] = {rec[3], rec[4], rec[5]};
                 const double split = rec[6];
                 const long long w7 = __double_as_longlong(rec[7]);
-                const int right = (int)w7;
-                const unsigned info = (unsigned)(w7 >> 32);
-                const int node = (int)cur;
+                const unsigned right = (unsigned)w7, info = (unsigned)(w7 >> 32);
+                const unsigned node = cur;
                 count(ST_VISITS, 1);
                 // cheap necessary condition first: check_aabb can only accept a ray that meets the
                 // box grown by eps (plus rounding); clear misses skip the three divisions
@@ -399,34 +402,33 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                                                     fabs(ma[0]) + fabs(ma[1]) + fabs(ma[2]));
                 if (!slab_hit(mi, ma, pad, s, inv, par) || !aabb_hit(mi, ma, s, v)) want_pop = true;
                 else {
+                    count(ST_TRIS, info >> 3); // the own list will be scanned (kdtree.cpp:122,131,137)
                     const int axis = info & 3;
-                    const bool hasL = (info >> 2) & 1, hasR = right > 0;
+                    const bool hasL = (info >> 2) & 1, hasR = right != 0;
                     const double sw = axis == 0 ? s[0] : axis == 1 ? s[1] : s[2];
                     const double vw = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
-                    int near = -1;
-                    unsigned farkind = 0; // 1: left child is the far one, 2: right child
+                    unsigned near = 0, farkind = 0; // farkind 1: left child is the far one, 2: right child
                     if (!hasL && !hasR) { /* leaf, or interior node whose triangles all straddle */ }
                     else if (sw < split) { // kdtree.cpp:119-127
-                        if (hasL) near = node + 1;
+                        if (hasL) near = node + 8;
                         if (hasR && vw > 0) farkind = 2;
                     } else if (sw > split) { // kdtree.cpp:128-136
                         if (hasR) near = right;
                         if (hasL && vw < 0) farkind = 1;
                     } else { // kdtree.cpp:137-141: on the plane, only the child the ray points into
-                        if (vw < 0 && hasL) near = node + 1;
+                        if (vw < 0 && hasL) near = node + 8;
                         else if (vw > 0 && hasR) near = right;
                     }
                     // the own list and the far child come after the near subtree; the frame's flag
                     // travels in the item and the near subtree starts with a clean one
-                    const unsigned after = IT_AFTER | ((unsigned)flag << 30) | (farkind << 28) | (unsigned)node;
+                    const unsigned after = IT_AFTER | ((unsigned)flag << 30) | (farkind << 28) | node;
                     flag = false;
-                    if (near >= 0) { push_item = after; next = (unsigned)near; }
+                    if (near != 0) { push_item = after; next = near; }
                     else next = after;
                 }
             }
         } else if (pick == K_CULL) {
-            if (run) { // ---- one record of a long own list's hierarchy: the boxes of its two children
-                count(ST_CULLS, 1);
+            if (run) { // ---- two child boxes of a list's hierarchy; for an after item, the list's start
                 const float2 f0 = __builtin_bit_cast(float2, rec[0]), f1 = __builtin_bit_cast(float2, rec[1]),
                              f2 = __builtin_bit_cast(float2, rec[2]), f3 = __builtin_bit_cast(float2, rec[3]),
                              f4 = __builtin_bit_cast(float2, rec[4]), f5 = __builtin_bit_cast(float2, rec[5]);
@@ -434,43 +436,39 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                 const double lo1[3] = {f3.x, f3.y, f4.x}, hi1[3] = {f4.y, f5.x, f5.y};
                 const long long w6 = __double_as_longlong(rec[6]);
                 const unsigned a = (unsigned)w6, b = (unsigned)(w6 >> 32);
-                const bool h0 = slab_hit(lo0, hi0, m2, s, inv, par), h1 = slab_hit(lo1, hi1, m2, s, inv, par);
-                if (h0 && h1) { push_item = b; next = a; }
-                else if (h0) next = a;
-                else if (h1) next = b;
-                else want_pop = true;
-            }
-        } else if (pick == K_AFTER) {
-            if (run) { // ---- near child finished: own list (kdtree.cpp:122,131,137), then far child
-                const int node = (int)(cur & NODE_MASK);
-                const unsigned farkind = (cur >> 28) & 3;
-                const bool near_hit = flag;            // what the near child's check() returned
-                flag = ((cur >> 30) & 1) | near_hit;   // back in the enclosing frame
-                const long long w5 = __double_as_longlong(rec[5]), w6 = __double_as_longlong(rec[6]);
-                const int first = (int)w5, right = (int)w6, count_ = (int)(w6 >> 32);
-                const unsigned root = (unsigned)(w5 >> 32); // first item of the list's hierarchy
-                count(ST_TRIS, (unsigned)count_);
-                if (farkind != 0 && !near_hit) { // kdtree.cpp:124,133: the far child comes after the list
-                    const unsigned far = farkind == 1 ? (unsigned)(node + 1) : (unsigned)right;
-                    if (sp < LDS_STACK) stk[sp][tid] = far;
-                    else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = far;
-                    sp++;
-                }
-                if (count_ == 0) want_pop = true;
-                else {
-                    list_first = first; list_end = first + count_;
-                    if (count_ <= SMALL_LIST) { // every triangle, in list order
-                        for (int i = count_ - 1; i > 0; i--) {
-                            const unsigned it = IT_TRI | (unsigned)(first + i);
-                            if (sp < LDS_STACK) stk[sp][tid] = it;
-                            else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = it;
-                            sp++;
+                bool boxes = true;
+                if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
+                    const long long w7 = __double_as_longlong(rec[7]);
+                    const unsigned right = (unsigned)w7, meta = (unsigned)(w7 >> 32);
+                    const unsigned node = cur & IDX28, farkind = (cur >> 28) & 3;
+                    const bool near_hit = flag;          // what the near child's check() returned
+                    flag = ((cur >> 30) & 1) | near_hit; // back in the enclosing frame
+                    if (farkind != 0 && !near_hit) push(sp, farkind == 1 ? node + 8 : right); // kdtree.cpp:124,133: after the list
+                    cur_list = (int)node;
+                    if (meta & LIST_SHORT) { // up to SMALL_LIST triangles, in list order
+                        boxes = false;
+                        const int n = (int)(meta & 0xFF);
+                        if (n == 0) want_pop = true;
+                        else {
+                            for (int i = n - 1; i > 0; i--) push(sp, a + 5u * (unsigned)i);
+                            next = a;
                         }
-                        next = IT_TRI | (unsigned)first;
-                    } else {
-                        m2 = 2.0 * (double)dscale * list_margin(rec[0], rec[1], rec[2], rec[3], rec[4], s);
-                        next = root;
+                    } else { // margin of this list's boxes, see list_margin()
+                        const double lmax2 = (double)__uint_as_float(meta);
+                        double cx = 0.5 * (fmin(lo0[0], lo1[0]) + fmax(hi0[0], hi1[0])), ex = fmax(hi0[0], hi1[0]) - fmin(lo0[0], lo1[0]);
+                        double cy = 0.5 * (fmin(lo0[1], lo1[1]) + fmax(hi0[1], hi1[1])), ey = fmax(hi0[1], hi1[1]) - fmin(lo0[1], lo1[1]);
+                        double cz = 0.5 * (fmin(lo0[2], lo1[2]) + fmax(hi0[2], hi1[2])), ez = fmax(hi0[2], hi1[2]) - fmin(lo0[2], lo1[2]);
+                        const double r2 = 0.5 * sqrt(ex * ex + ey * ey + ez * ez) + sqrt(lmax2);
+                        m2 = 2.0 * (double)dscale * list_margin(cx, cy, cz, 1e-9 * lmax2 + 1e-10, r2, s);
                     }
+                }
+                if (boxes) {
+                    count(ST_CULLS, 1);
+                    const bool h0 = slab_hit(lo0, hi0, m2, s, inv, par), h1 = slab_hit(lo1, hi1, m2, s, inv, par);
+                    if (h0 && h1) { push_item = b; next = a; }
+                    else if (h0) next = a;
+                    else if (h1) next = b;
+                    else want_pop = true;
                 }
             }
         } else if (pick == K_TRI) {
@@ -479,12 +477,12 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                 const double t = tri_hit(mk(rec[0], rec[1], rec[2]), mk(rec[3], rec[4], rec[5]), mk(rec[6], rec[7], rec[8]), o, d);
                 count(ST_DONE, 1);
                 if (t > EPS) {
-                    const int pos = (int)(cur & IDX29);
-                    const int rk = (int)(__double_as_longlong(rec[9]) >> 32);
+                    const long long w9 = __double_as_longlong(rec[9]);
+                    const int rk = (int)(w9 >> 32);
                     // strict < keeps the earlier of two equal distances; inside one list "earlier"
                     // is the lower rank, across lists it is the list visited first
-                    if (t < best_t || (t == best_t && best_pos >= list_first && best_pos < list_end && rk < best_rank)) {
-                        best_t = t; best_pos = pos; best_rank = rk;
+                    if (t < best_t || (t == best_t && best_list == cur_list && rk < best_rank)) {
+                        best_t = t; best_pos = (int)w9; best_rank = rk; best_list = cur_list;
                     }
                     if (t < 1e10) flag = true;
                 }
@@ -510,7 +508,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                     const bool fo = to < 1e10, fs = ts < 1e10;
                     if (TRACE) {
                         if (fo && !(ts < to)) count(ST_SHADES, 1);
-                        tri_id[outk] = fo ? S.tris[tpos].gid : -1;
+                        tri_id[outk] = fo ? S.tshade[tpos].gid : -1;
                         tri_t[outk] = to;
                         sph_id[outk] = fs ? ids : -1;
                         sph_t[outk] = ts;
@@ -531,7 +529,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                             x = o + d * to;
                             n = ld3(sh->nc);
                             f = ld3(sh->col); type = sh->type; lig = ld3(sh->lig);
-                            if (primary && sub == 0 && smp == 0 && prim) prim[outk] = S.tris[tpos].gid;
+                            if (primary && sub == 0 && smp == 0 && prim) prim[outk] = sh->gid;
                             count(ST_SHADES, 1);
                         }
                         const d3 nl = dot(n, d) < 0 ? n : n * -1.0;
@@ -668,42 +666,32 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                     inv[0] = (par & 1) ? 0.0 : 1.0 / v[0]; inv[1] = (par & 2) ? 0.0 : 1.0 / v[1]; inv[2] = (par & 4) ? 0.0 : 1.0 / v[2];
                     const float dl = (float)sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * 1.000001f;
                     dscale = dl > 1.0f ? dl : 1.0f;
-                    best_t = 1e20; best_pos = -1; best_rank = 0; list_first = 0; list_end = 0;
+                    best_t = 1e20; best_pos = -1; best_rank = 0; best_list = -1; cur_list = -1;
                     sp = 0; flag = false;
                     have_hit = true;
                     count(ST_RAYS, 1);
-                    next = 0; // the root node
-                }
+                    // next stays 0: the root node
+                } else want_pop = true; // sp is 0: the lane stays idle (done, or out of work)
             }
         }
 
         // ---- common tail for the lanes that ran: push, pop, fetch the next item's record
-        if (run && kind != K_DONE) {
-            bool fetch = true;
-            if (pick == K_SHADE) fetch = have_hit; // a new traversal starts at the root, otherwise the lane is done or idle
-            if (push_item != 0) {
-                if (sp < LDS_STACK) stk[sp][tid] = push_item;
-                else S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread] = push_item;
-                sp++;
-            }
+        if (run) {
+            if (push_item != 0) push(sp, push_item);
             if (want_pop) {
-                if (sp == 0) { kind = K_SHADE; fetch = false; } // the traversal is complete
+                if (sp == 0) next = 0xFFFFFFFFu; // the traversal is complete
                 else {
                     sp--;
                     next = sp < LDS_STACK ? stk[sp][tid] : S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread];
                 }
             }
-            if (fetch) {
-                cur = next;
-                kind = item_kind(cur);
-                const char *base = kind == K_NODE ? (const char *)S.nodes : kind == K_CULL ? (const char *)S.cull
-                                   : kind == K_AFTER ? (const char *)S.lists : (const char *)S.tris;
-                const unsigned idx = kind == K_AFTER ? (cur & NODE_MASK) : (cur & IDX29);
-                const double2 *p = (const double2 *)(base + (size_t)idx * (kind == K_TRI ? 80u : 64u));
-                const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                rec[0] = q0.x; rec[1] = q0.y; rec[2] = q1.x; rec[3] = q1.y; rec[4] = q2.x; rec[5] = q2.y; rec[6] = q3.x; rec[7] = q3.y;
-                if (kind == K_TRI) { const double2 q4 = p[4]; rec[8] = q4.x; rec[9] = q4.y; }
-            }
+            if (kind != K_DONE) kind = next == 0xFFFFFFFFu ? K_SHADE : (next & IT_AFTER) ? K_CULL : (int)((next >> 29) & 3);
+            cur = next == 0xFFFFFFFFu ? 0u : next;
+            const unsigned g = (cur & IT_AFTER) ? (cur & IDX28) + 4u : (cur & IDX29);
+            const double2 *p = (const double2 *)(S.pool + (size_t)g * 16);
+            const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+            rec[0] = q0.x; rec[1] = q0.y; rec[2] = q1.x; rec[3] = q1.y; rec[4] = q2.x; rec[5] = q2.y; rec[6] = q3.x; rec[7] = q3.y;
+            rec[8] = q4.x; rec[9] = q4.y;
         }
     }
 
@@ -747,7 +735,7 @@ int fail(int code, const char *fmt, ...) {
 struct rt_scene {
     int dev = 0;
     DevScene d{};
-    void *nodes = nullptr, *first = nullptr, *cull = nullptr, *tris = nullptr, *tshade = nullptr, *sph = nullptr, *sshade = nullptr;
+    void *pool = nullptr, *tshade = nullptr, *sph = nullptr, *sshade = nullptr;
     void *ovf = nullptr, *lstate = nullptr;
     int tree_depth = 0;
     int grid = 0;               // persistent workgroups
@@ -764,25 +752,30 @@ struct rt_scene {
 namespace {
 
 // Culling hierarchy for one long own list: median splits of the triangle centroids along the
-// widest axis down to single triangles.  A CullRec holds the boxes of its two children (exact
-// bounds rounded OUTWARD to single precision) and the children as work items, so one 64-byte fetch
-// decides both subtrees and a triangle is only fetched when its own box is met.
+// widest axis down to single triangles.  Every inner record holds the boxes of its two children
+// (exact bounds rounded OUTWARD to single precision) and the children as work items, so one
+// 64-byte fetch decides both subtrees and a triangle is only fetched when its own box is met.
+// The root of a list's hierarchy is stored in the node's ListRec.
 // `order[first..first+count)` is permuted into the hierarchy's left-to-right leaf order.
 struct CullTri { double lo[3], hi[3], c[3]; int src; };
 
 float f_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; }
 float f_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; }
 
-// returns the work item for the range [a, b) and its exact bounds in lo/hi
-unsigned cull_rec(std::vector<CullRec> &out, std::vector<CullTri> &bt, int a, int b, int first, int depth, int &max_depth,
-                  double lo[3], double hi[3]) {
-    if (depth > max_depth) max_depth = depth;
-    if (b - a == 1) {
-        for (int k = 0; k < 3; k++) { lo[k] = bt[a].lo[k]; hi[k] = bt[a].hi[k]; }
-        return IT_TRI | (unsigned)(first + a);
-    }
-    const size_t me = out.size();
-    out.emplace_back();
+struct CullBuild {
+    std::vector<CullRec> *out;
+    std::vector<CullTri> *bt;
+    unsigned cull_base, tri_base; // granules
+    int first;                    // list position of the range's first triangle
+    int max_depth;
+};
+
+unsigned cull_item(CullBuild &B, int a, int b, int depth, double lo[3], double hi[3]);
+
+// splits [a, b) (b - a >= 2), builds both halves, fills the two-box record `r`, returns the union box
+void cull_split(CullBuild &B, int a, int b, int depth, float (&lo0)[3], float (&hi0)[3], float (&lo1)[3], float (&hi1)[3],
+                unsigned &ia, unsigned &ib, double lo[3], double hi[3]) {
+    std::vector<CullTri> &bt = *B.bt;
     double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
     for (int i = a; i < b; i++)
         for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], bt[i].c[k]); chi[k] = std::max(chi[k], bt[i].c[k]); }
@@ -794,20 +787,35 @@ unsigned cull_rec(std::vector<CullRec> &out, std::vector<CullTri> &bt, int a, in
         return x.c[ax] < y.c[ax] || (x.c[ax] == y.c[ax] && x.src < y.src);
     });
     double l0[3], h0[3], l1[3], h1[3];
-    const unsigned ia = cull_rec(out, bt, a, mid, first, depth + 1, max_depth, l0, h0);
-    const unsigned ib = cull_rec(out, bt, mid, b, first, depth + 1, max_depth, l1, h1);
-    CullRec &r = out[me];
+    ia = cull_item(B, a, mid, depth + 1, l0, h0);
+    ib = cull_item(B, mid, b, depth + 1, l1, h1);
     for (int k = 0; k < 3; k++) {
-        r.lo0[k] = f_down(l0[k]); r.hi0[k] = f_up(h0[k]);
-        r.lo1[k] = f_down(l1[k]); r.hi1[k] = f_up(h1[k]);
+        lo0[k] = f_down(l0[k]); hi0[k] = f_up(h0[k]);
+        lo1[k] = f_down(l1[k]); hi1[k] = f_up(h1[k]);
         lo[k] = std::min(l0[k], l1[k]); hi[k] = std::max(h0[k], h1[k]);
     }
-    r.a = ia; r.b = ib; r.pad = 0;
-    return IT_CULL | (unsigned)me;
 }
 
-void build_cull(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<CullRec> &cull, ListRec &li,
-                int &max_depth) {
+// the work item for the range [a, b) and its exact bounds
+unsigned cull_item(CullBuild &B, int a, int b, int depth, double lo[3], double hi[3]) {
+    if (depth > B.max_depth) B.max_depth = depth;
+    if (b - a == 1) {
+        const CullTri &t = (*B.bt)[a];
+        for (int k = 0; k < 3; k++) { lo[k] = t.lo[k]; hi[k] = t.hi[k]; }
+        return IT_TRI | (B.tri_base + 5u * (unsigned)(B.first + a));
+    }
+    const size_t me = B.out->size();
+    B.out->emplace_back();
+    CullRec r;
+    cull_split(B, a, b, depth, r.lo0, r.hi0, r.lo1, r.hi1, r.a, r.b, lo, hi);
+    r.pad = 0;
+    (*B.out)[me] = r;
+    return IT_CULL | (B.cull_base + 4u * (unsigned)me);
+}
+
+// fills the ListRec of a list longer than SMALL_LIST and permutes order[first..first+count)
+void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<CullRec> &cull, unsigned cull_base,
+                unsigned tri_base, ListRec &li, int &max_depth) {
     std::vector<CullTri> bt((size_t)count);
     double lmax2 = 0;
     for (int j = 0; j < count; j++) {
@@ -825,24 +833,20 @@ void build_cull(const rt_scene_desc *D, int first, int count, std::vector<int> &
             lmax2 = std::max(lmax2, l2);
         }
     }
-    int depth = 0;
+    CullBuild B = {&cull, &bt, cull_base, tri_base, first, 0};
     double lo[3], hi[3];
-    li.root = cull_rec(cull, bt, 0, count, first, 1, depth, lo, hi);
-    max_depth = std::max(max_depth, depth);
+    cull_split(B, 0, count, 1, li.lo0, li.hi0, li.lo1, li.hi1, li.a, li.b, lo, hi);
+    max_depth = std::max(max_depth, B.max_depth);
     for (int j = 0; j < count; j++) order[first + j] = bt[j].src;
-    double r2 = 0;
-    for (int k = 0; k < 3; k++) {
-        li.c[k] = 0.5 * (lo[k] + hi[k]);
-        r2 += 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]);
-    }
-    li.k2 = 1e-9 * lmax2 + 1e-10;         // see list_margin()
-    li.r2 = std::sqrt(r2) + std::sqrt(lmax2);
+    float l2f = f_up(lmax2); // the margin grows with it: round up
+    if (!(l2f >= 0.0f)) l2f = INFINITY;
+    memcpy(&li.meta, &l2f, 4);
 }
 
 int validate(const rt_scene_desc *D) {
     if (!D) return fail(RT_E_INVALID, "desc is NULL");
     if (D->n_nodes < 1) return fail(RT_E_INVALID, "n_nodes must be >= 1 (got %d)", D->n_nodes);
-    if ((unsigned)D->n_nodes > NODE_MASK) return fail(RT_E_LIMIT, "n_nodes %d exceeds %u", D->n_nodes, NODE_MASK);
+    if (D->n_nodes > (1 << 25)) return fail(RT_E_LIMIT, "n_nodes %d exceeds %d", D->n_nodes, 1 << 25);
     if (D->n_tris < 0 || D->n_spheres < 0) return fail(RT_E_INVALID, "negative primitive count");
     if (D->n_list != D->n_tris) return fail(RT_E_INVALID, "n_list (%d) must equal n_tris (%d)", D->n_list, D->n_tris);
     if (!D->node_box || !D->node_split || !D->node_axis || !D->node_left || !D->node_right || !D->node_first || !D->node_count)
@@ -1000,41 +1004,52 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (dev < 0 || dev >= ndev) return fail(RT_E_INVALID, "device %d not in [0,%d)", dev, ndev);
     HIP_TRY(hipSetDevice(dev));
 
-    std::vector<NodeRec> nodes((size_t)D->n_nodes);
-    std::vector<ListRec> lists((size_t)D->n_nodes);
+    // pool layout in 16-byte granules: nodes (NodeRec + ListRec = 8 each), cull records (4), triangles (5)
+    size_t n_cull = 0;
+    for (int i = 0; i < D->n_nodes; i++)
+        if (D->node_count[i] > SMALL_LIST) n_cull += (size_t)D->node_count[i] - 2; // inner records below the root
+    const size_t g_cull = 8 * (size_t)D->n_nodes, g_tri = g_cull + 4 * n_cull, g_end = g_tri + 5 * (size_t)D->n_tris + 2;
+    if (g_cull > (size_t)IDX28 || g_end > (size_t)IDX29) return fail(RT_E_LIMIT, "scene too large for the 29-bit record index");
+    std::vector<char> pool(g_end * 16, 0);
     std::vector<CullRec> cull;
+    cull.reserve(n_cull);
     std::vector<int> order((size_t)D->n_list); // device position -> entry of list_tri
     for (int i = 0; i < D->n_list; i++) order[i] = i;
     int cull_depth = 0;
     for (int i = 0; i < D->n_nodes; i++) {
-        NodeRec &n = nodes[i];
+        NodeRec n;
         for (int k = 0; k < 3; k++) { n.mi[k] = D->node_box[6 * i + k]; n.ma[k] = D->node_box[6 * i + 3 + k]; }
         n.split = D->node_split[i];
-        n.right = D->node_right[i] > 0 ? D->node_right[i] : 0;
-        n.info = (unsigned)D->node_axis[i] | (D->node_left[i] >= 0 ? 4u : 0u);
-        ListRec &li = lists[i];
-        li.first = D->node_first[i];
-        li.root = 0;
+        n.right = D->node_right[i] > 0 ? 8u * (unsigned)D->node_right[i] : 0u;
+        n.info = (unsigned)D->node_axis[i] | (D->node_left[i] >= 0 ? 4u : 0u) | ((unsigned)D->node_count[i] << 3);
+        ListRec li;
+        memset(&li, 0, sizeof(li));
         li.right = n.right;
-        li.count = D->node_count[i];
-        li.c[0] = li.c[1] = li.c[2] = 0; li.k2 = 0; li.r2 = 0; li.pad = 0;
-        if (D->node_count[i] > SMALL_LIST) build_cull(D, D->node_first[i], D->node_count[i], order, cull, li, cull_depth);
+        const int cnt = D->node_count[i], first = D->node_first[i];
+        if (cnt > SMALL_LIST) build_list(D, first, cnt, order, cull, (unsigned)g_cull, (unsigned)g_tri, li, cull_depth);
+        else {
+            li.meta = LIST_SHORT | (unsigned)cnt;
+            li.a = IT_TRI | ((unsigned)g_tri + 5u * (unsigned)first);
+        }
+        memcpy(&pool[(size_t)i * 128], &n, 64);
+        memcpy(&pool[(size_t)i * 128 + 64], &li, 64);
     }
-    if (cull.size() > (size_t)IDX29 || (unsigned)D->n_tris > IDX29) return fail(RT_E_LIMIT, "scene too large for 29-bit item indices");
-    std::vector<TriRec> tris((size_t)D->n_tris);
+    if (cull.size() != n_cull) return fail(RT_E_INVALID, "internal: culling hierarchy size mismatch");
+    if (n_cull) memcpy(&pool[g_cull * 16], cull.data(), n_cull * sizeof(CullRec));
     std::vector<TriShade> tsh((size_t)D->n_tris);
     for (int pos = 0; pos < D->n_list; pos++) {
         const int rank = order[pos];
         const int g = D->list_tri[rank];
         const double *v = D->tri_verts + 9 * (size_t)g;
-        TriRec &t = tris[pos];
+        TriRec t;
         for (int k = 0; k < 3; k++) {
             t.p0[k] = v[k];
             t.e1[k] = v[3 + k] - v[k]; // polygon.h:39
             t.e2[k] = v[6 + k] - v[k]; // polygon.h:40
         }
-        t.gid = g;
+        t.pos = pos;
         t.rank = rank;
+        memcpy(&pool[(g_tri + 5 * (size_t)pos) * 16], &t, sizeof(t));
         TriShade &h = tsh[pos];
         for (int k = 0; k < 3; k++) {
             h.nc[k] = D->tri_nc[3 * (size_t)g + k];
@@ -1042,7 +1057,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
             h.lig[k] = D->tri_lig[3 * (size_t)g + k];
         }
         h.type = D->tri_type[g];
-        h.pad = 0;
+        h.gid = g;
     }
     std::vector<SphGeom> sg((size_t)D->n_spheres);
     std::vector<SphShade> ss((size_t)D->n_spheres);
@@ -1058,10 +1073,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (!s) return fail(RT_E_NOMEM, "out of host memory");
     s->dev = dev;
     s->tree_depth = D->tree_depth;
-    rc = upload(&s->nodes, nodes);
-    if (!rc) rc = upload(&s->first, lists);
-    if (!rc) rc = upload(&s->cull, cull);
-    if (!rc) rc = upload(&s->tris, tris);
+    rc = upload(&s->pool, pool);
     if (!rc) rc = upload(&s->tshade, tsh);
     if (!rc) rc = upload(&s->sph, sg);
     if (!rc) rc = upload(&s->sshade, ss);
@@ -1075,7 +1087,8 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         per_cu = 2;
     s->grid = pr.multiProcessorCount * per_cu;
     const int n_threads = s->grid * BLOCK;
-    const int need_depth = D->tree_depth + cull_depth + SMALL_LIST + 2; // main frames plus one list's culling walk on top
+    // one after item per tree level, the far child, one list's hierarchy walk or short list on top
+    const int need_depth = D->tree_depth + cull_depth + SMALL_LIST + 3;
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK : 0;
     hipError_t e = hipSuccess;
     if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_threads * sizeof(unsigned));
@@ -1089,17 +1102,12 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         rt_free_scene(s);
         return fail(RT_E_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
     }
-    s->d.nodes = (const NodeRec *)s->nodes;
-    s->d.lists = (const ListRec *)s->first;
-    s->d.cull = (const CullRec *)s->cull;
-    s->d.tris = (const TriRec *)s->tris;
+    s->d.pool = (const char *)s->pool;
     s->d.tshade = (const TriShade *)s->tshade;
     s->d.sph = (const SphGeom *)s->sph;
     s->d.sshade = (const SphShade *)s->sshade;
     s->d.ovf = (unsigned *)s->ovf;
     s->d.lstate = (double *)s->lstate;
-    s->d.n_nodes = D->n_nodes;
-    s->d.n_tris = D->n_tris;
     s->d.n_sph = D->n_spheres;
     s->d.ovf_depth = ovf_depth;
     s->d.n_threads = n_threads;
@@ -1110,7 +1118,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->nodes, s->first, s->cull, s->tris, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->d_counter, s->d_stats, s->d_tiles};
+    void *ptrs[] = {s->pool, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->d_counter, s->d_stats, s->d_tiles};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -1134,7 +1142,7 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
     HIP_TRY(hipMemcpy(h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(s->d_stats, 0, sizeof(h)));
     stats->rays = h[0]; stats->node_visits = h[1]; stats->tri_tests = h[2]; stats->sph_tests = h[3]; stats->tri_shades = h[4];
-    stats->tri_tests_done = h[5]; stats->cull_tests = h[6];
+    stats->tri_tests_done = h[5]; stats->cull_tests = h[6]; stats->sched_steps = h[7]; stats->sched_lanes = h[8];
     return RT_OK;
 }
 
