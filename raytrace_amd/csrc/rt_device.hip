@@ -38,7 +38,7 @@
 // order among equals" plus "does any t < 1e10 exist", and both only depend on the triangles that
 // Polygon::intersect accepts.  So each long list gets a small bounding-box hierarchy, built at
 // upload, whose boxes are inflated by a margin that provably exceeds how far outside a triangle
-// the floating-point Moller-Trumbore test can still accept a ray (see list_margin()); subtrees
+// the floating-point Moller-Trumbore test can still accept a ray (see ray_margin_factor()); subtrees
 // whose inflated box the ray misses are skipped, the surviving triangles go through the unchanged
 // exact test, and ties are broken by the stored list rank.  Results are identical by construction.
 #include <hip/hip_runtime.h>
@@ -57,12 +57,14 @@
 namespace {
 
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 3 // wavefronts per SIMD the register allocation is bounded for
+#define RT_MIN_WAVES 2 // wavefronts per SIMD the register allocation is bounded for
 #endif
 
 constexpr double EPS = 1e-5;  // point.h:7
-constexpr int BLOCK = 256;    // threads per workgroup (4 wavefronts)
-constexpr int LDS_STACK = 24; // traversal-stack levels kept in LDS
+constexpr int WAVE = 64;          // threads per workgroup: one wavefront
+constexpr int RAYS_PER_LANE = 2;  // ray slots each lane chooses from
+constexpr int SLOTS = WAVE * RAYS_PER_LANE; // ray slots per workgroup
+constexpr int LDS_STACK = 16;     // traversal-stack levels kept in LDS
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 constexpr int N_STATS = 9;
 constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly, longer ones get a hierarchy
@@ -93,16 +95,16 @@ static_assert(sizeof(CullRec) == 64, "CullRec must be 64 bytes");
 
 struct __attribute__((aligned(16))) ListRec { // a node's own list (KdTree::node)
     float lo0[3], hi0[3], lo1[3], hi1[3]; // long lists only
-    unsigned a, b;  // long list: the two child items; short list: a = item of the first triangle
+    unsigned a, b;  // long list: the two child items; short list: a = chained item of the first triangle
     unsigned right; // granule of the node's right child (0 = none), for the far-child step
-    unsigned meta;  // long list: bits of (float) squared longest triangle edge; short: LIST_SHORT | length
+    unsigned meta;  // long list: bits of the (float) margin coefficient K; short: LIST_SHORT | length
 };
 static_assert(sizeof(ListRec) == 64, "ListRec must be 64 bytes");
 constexpr unsigned LIST_SHORT = 0x80000000u;
 
 struct __attribute__((aligned(16))) TriRec {
     double p0[3], e1[3], e2[3];
-    int pos;  // index of the triangle's TriShade
+    int pos;  // index of the triangle's TriShade; TRI_LAST set on the last triangle of an own list
     int rank; // position in the reference's list order (decides between equal distances)
 };
 static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
@@ -123,11 +125,14 @@ struct DevScene {
     const TriShade *tshade;
     const SphGeom *sph;
     const SphShade *sshade;
-    unsigned *ovf;  // overflow stack [ovf_depth][n_threads]
-    double *lstate; // per-lane path state that is only touched between rays [LS_SLOTS][n_threads]
+    unsigned *ovf;  // overflow stack [ovf_depth][n_slots]
+    double *lstate; // per-slot state kept in HBM [LS_WORDS][n_slots]
+    double cen[3]; // centre of the scene's vertex box
+    double reach;  // its summed half extents + the scene's longest triangle edge
+    double absn;   // |centre|_1 + summed half extents
     int n_sph;
     int ovf_depth;
-    int n_threads;
+    int n_slots;
 };
 
 struct DevCamera {
@@ -215,34 +220,35 @@ __device__ __forceinline__ double tri_hit(d3 p0, d3 E1, d3 E2, d3 o, d3 d) {
 // and det is at most ~40 ulp * |T| * L^2 (T = origin - p0, L = longest edge), and the acceptance
 // needs det >= eps = 1e-5, so in barycentric terms the slack is <= 40 * 1.1e-16 * |T| * L^2 / 1e-5
 // and the accepted point lies within 4.4e-10 * L^2 * (|T| + L) of the triangle.  The margin used is
-// (1e-9 * L^2 + 1e-10) * (|o - c| + R + L) with c, R the list box centre / half-diagonal (|T| <=
-// |o - c| + R), i.e. more than twice that bound; the boxes are then inflated by twice the margin
-// again, which also swallows the few-ulp error of the slab arithmetic itself.  The bound is for a
+// (1e-9 * L^2 + 1e-10) * B with B >= |T| + L for every triangle of the scene: B = |o - C|_1 + H + Lg
+// (C, H the centre and the summed half extents of the scene's vertex box, Lg the longest edge of
+// the scene), i.e. more than twice that bound; the boxes are then inflated by twice the margin
+// again, which also swallows the few-ulp error of the slab arithmetic itself (a term proportional
+// to the absolute coordinates covers scenes far from the coordinate origin).  The bound is for a
 // unit direction; the rounding errors grow with |d| while the det cut does not, so the margin is
-// multiplied by max(1, |d|).
-__device__ __forceinline__ double list_margin(double cx, double cy, double cz, double k2, double r2, const double (&s)[3]) {
-    const double dx = s[0] - cx, dy = s[1] - cy, dz = s[2] - cz;
-    return k2 * (sqrt(dx * dx + dy * dy + dz * dz) + r2);
+// multiplied by max(1, |d|).  Per list only K = 2 * (1e-9 * L^2 + 1e-10) is stored, per ray the
+// factor G = max(1, |d|) * B + 1e-5 * (|o|_1 + |C|_1 + H); a list's inflation is K * G.
+__device__ __forceinline__ float ray_margin_factor(const double (&cen)[3], double reach, double absn, double ox, double oy, double oz,
+                                                   double dlen) {
+    const double b = fabs(ox - cen[0]) + fabs(oy - cen[1]) + fabs(oz - cen[2]) + reach;
+    const double g = (dlen > 1.0 ? dlen : 1.0) * b + 1e-5 * (fabs(ox) + fabs(oy) + fabs(oz) + absn);
+    return __double2float_ru(g * 1.000001);
 }
 
 // Conservative ray (t >= 0) versus inflated box: never false for a ray the exact triangle test
-// could accept; a false positive only costs an extra exact test.
+// could accept; a false positive only costs an extra exact test.  `inv` holds 1/direction, or
+// 1e300 for a (nearly) zero component: the products then overflow to -inf/+inf on the two sides
+// of the origin, which makes that axis accept exactly the origins inside its slab.
 __device__ __forceinline__ bool slab_hit(const double (&lo0)[3], const double (&hi0)[3], double m2, const double (&s)[3],
-                                         const double (&inv)[3], unsigned par) {
+                                         const double (&inv)[3]) {
     double tmin = 0.0, tmax = 1e300;
-    bool ok = true;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const double lo = lo0[i] - m2, hi = hi0[i] + m2;
-        if ((par >> i) & 1) { if (s[i] < lo || s[i] > hi) ok = false; }
-        else {
-            const double t1 = (lo - s[i]) * inv[i], t2 = (hi - s[i]) * inv[i];
-            const double ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
-            tmin = ta > tmin ? ta : tmin;
-            tmax = tb < tmax ? tb : tmax;
-        }
+        const double t1 = ((lo0[i] - m2) - s[i]) * inv[i], t2 = ((hi0[i] + m2) - s[i]) * inv[i];
+        tmin = fmax(tmin, fmin(t1, t2));
+        tmax = fmin(tmax, fmax(t1, t2));
     }
-    return ok && tmin <= tmax;
+    return tmin <= tmax;
 }
 
 // sphere.cpp:3-14 over sphere.h:13-21: scan from the last sphere down, strict <
@@ -264,8 +270,6 @@ __device__ __forceinline__ void trace_spheres(const DevScene &S, d3 o, d3 d, dou
         if (t < ts) { ts = t; ids = i; }
     }
 }
-
-struct Pending { d3 o, d, thr; int depth; int into; };
 
 __device__ __forceinline__ double clamp01(double x) { return x < 0 ? 0 : x > 1 ? 1 : x; } // raytrace.cpp:28-31
 
@@ -291,118 +295,137 @@ __device__ __forceinline__ void sincos_2pi(double x, double &sn, double &cs) {
     cs = q == 0 ? kc : q == 1 ? -ks : q == 2 ? -kc : ks;
 }
 
-// A traversal work item, 32 bits; the per-lane stack holds these.  The low bits are the granule
+// A traversal work item, 32 bits; the per-ray stack holds these.  The low bits are the granule
 // of the item's record in the pool.
 //   node item   : granule (29 bits), kind bits 00            enter the node: KdTree::check
 //   cull item   : IT_CULL | granule                          one inner record of a list's hierarchy
-//   tri item    : IT_TRI | granule                           one exact triangle test
+//   tri item    : IT_TRI | chain << 28 | granule (28 bits)   one exact triangle test; with `chain` the next
+//                 triangle of the list follows directly, up to the one marked last (short lists)
 //   after item  : IT_AFTER | flag << 30 | far << 28 | node granule (28 bits)
 //                 the node's near child is done: own list, then the far child; `flag` is the
 //                 enclosing frame's "has a hit" so far.  Its record is the node's ListRec.
-constexpr unsigned IT_CULL = 1u << 29, IT_TRI = 2u << 29, IT_AFTER = 1u << 31, IDX29 = 0x1FFFFFFFu, IDX28 = 0x0FFFFFFFu;
+constexpr unsigned IT_CULL = 1u << 29, IT_TRI = 2u << 29, IT_CHAIN = 1u << 28, IT_AFTER = 1u << 31, IDX29 = 0x1FFFFFFFu,
+                   IDX28 = 0x0FFFFFFFu;
+constexpr unsigned TRI_LAST = 0x80000000u; // in TriRec::pos: last triangle of its own list
+constexpr unsigned IT_END = 0xFFFFFFFFu; // "the stack is empty": the traversal is complete
 enum { K_NODE = 0, K_CULL = 1, K_TRI = 2, K_SHADE = 3, K_DONE = 4 };
 enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, ST_ITERS, ST_LANES };
-// slots of the per-lane state kept in HBM (one 8-byte word each, [slot][thread] so lanes coalesce):
-// everything that is only touched between two rays
-enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PIX = 13, LS_SLOTS = 14 };
+// Words of a ray slot's state kept in HBM (8 bytes each, [word][slot] so lanes coalesce): what
+// only the shading step touches, plus the ray direction (read together with a record).
+//   LS_PST  low: depth (bits 0-19), pending branches (20-22), sub-pixel (23-24), into (25),
+//           primary (26), a traversal is waiting to be shaded (27); high: sample index
+//   LS_OUT  low: index in the packed output (render) / ray index (trace); high: pixel x << 16 | y
+//   LS_PEND parked glass branches, PEND_WORDS each: origin, direction, throughput, depth | into << 32
+enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13, LS_OUT = 14, LS_V = 15, LS_PEND = 18 };
+constexpr int PEND_WORDS = 10;
+constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
+// per-slot flags word in LDS: stack pointer (bits 0-7), the frame's "has a hit" flag (8)
+constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u;
 
 // The whole path -- camera ray, KdTree::check without recursion, check_node, sphere scan, radiance()
-// as a loop -- runs as ONE loop per wavefront in which every lane is a small state machine, and in
-// every iteration the wavefront executes the one kind of work that most of its lanes are waiting
-// for:
+// as a loop -- is cut into steps of four kinds:
 //     node   enter a kd-tree node: check_aabb, choose near / far child          (kdtree.cpp:111-141)
 //     cull   two child boxes of a long own list's culling hierarchy; the first such step of a list
 //            also does the bookkeeping of "the node's near child has returned"   (kdtree.cpp:122-125)
 //     tri    one exact triangle test                                            (kdtree.cpp:101-107)
 //     shade  sphere scan, material, next ray / next path / next pixel           (raytrace.cpp:41-95,196-205)
-// Lanes that are waiting for another kind simply sit out the iteration, so they pile up until
-// their kind wins the vote; each executed instruction therefore has many active lanes although
-// the 64 rays of a packet diverge completely after the first bounce.  A lane fetches the record
-// of its next item as soon as the item is known, so the load is usually complete by the time the
-// lane's kind is scheduled.
+// A workgroup is ONE wavefront that owns SLOTS = 2 x 64 ray slots.  A slot is a complete path
+// tracer state: its ray, running best hit, flags and the top of its traversal stack live in LDS
+// ([field][slot], conflict free), the shading-only state lives in HBM, and NOTHING about a ray is
+// held in registers between steps.  Each iteration the wavefront votes for the kind of step that
+// most lanes can serve from one of their two slots, every such lane runs that step for its slot
+// (state from LDS, record from the pool, both loads issued together), and writes the few words
+// that changed.  Because the 64 rays of a packet diverge completely after the first bounce, this
+// keeps many lanes active per executed instruction, and the step bodies are straight-line code
+// without loop-carried registers.
 //
-// TRACE = false: lanes pull pixels (8x8 blocks, one lane per pixel) from an atomic counter and
-// run each pixel's 4*samps paths in the reference's order.  TRACE = true: lanes pull explicit rays
+// TRACE = false: slots pull pixels (8x8 blocks, one slot per pixel) from an atomic counter and
+// run each pixel's 4*samps paths in the reference's order.  TRACE = true: slots pull explicit rays
 // and report the nearest triangle / sphere (raytrace.cpp:46-47).
 template <bool TRACE>
-__global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCamera cam, rt_params P, const DevTile *tiles, int n_tiles,
-                                                unsigned n_work, unsigned *counter, double *rgb, int *prim, const double *rays,
-                                                int *tri_id, double *tri_t, int *sph_id, double *sph_t,
-                                                unsigned long long *gstats) {
-    __shared__ unsigned stk[LDS_STACK][BLOCK];
-    __shared__ unsigned long long sacc[N_STATS][BLOCK];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int gthread = blockIdx.x * BLOCK + tid;
+__global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCamera cam, rt_params P, const DevTile *tiles, int n_tiles,
+                                                             unsigned n_work, unsigned *counter, double *rgb, int *prim,
+                                                             const double *rays, int *tri_id, double *tri_t, int *sph_id,
+                                                             double *sph_t, unsigned long long *gstats) {
+    __shared__ double2 sA[SLOTS];       // origin x, y
+    __shared__ double2 sB[SLOTS];       // origin z, best distance so far
+    __shared__ double2 sC[SLOTS];       // 1/direction x, y
+    __shared__ double2 sD[SLOTS];       // 1/direction z; float culling margin of the current list, float margin factor of the ray
+    __shared__ uint4 sH[SLOTS];         // current item, flags word, current list (node granule), best triangle (TriShade index)
+    __shared__ uint2 sG[SLOTS];         // best triangle's list rank, best triangle's list
+    __shared__ unsigned stk[LDS_STACK][SLOTS];
+    const int lane = threadIdx.x;
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-    for (int k = 0; k < N_STATS; k++) sacc[k][tid] = 0;
-    // work counters live in LDS (one add per event, no registers held across the loop)
-    auto count = [&](int k, unsigned n) __attribute__((always_inline)) {
-        __hip_atomic_fetch_add(&sacc[k][tid], (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    };
-    auto push = [&](int &sp_, unsigned item) __attribute__((always_inline)) {
-        if (sp_ < LDS_STACK) stk[sp_][tid] = item;
-        else S.ovf[(size_t)(sp_ - LDS_STACK) * S.n_threads + gthread] = item;
-        sp_++;
-    };
-    double *const ls = S.lstate + gthread;
-    const size_t lss = (size_t)S.n_threads;
-    auto ls_get3 = [&](int slot) __attribute__((always_inline)) { return mk(ls[slot * lss], ls[(slot + 1) * lss], ls[(slot + 2) * lss]); };
-    auto ls_put3 = [&](int slot, d3 a) __attribute__((always_inline)) { ls[slot * lss] = a.x; ls[(slot + 1) * lss] = a.y; ls[(slot + 2) * lss] = a.z; };
+    const size_t lss = (size_t)S.n_slots;
+    const size_t gslot0 = (size_t)blockIdx.x * SLOTS;
 
-    // ---- per-lane state held in registers across the loop: the ray, the current item and its
-    // record, the running best, the stack pointer
-    int kind = K_SHADE;
-    double s[3] = {0, 0, 0}, v[3] = {0, 0, 1}, inv[3] = {0, 0, 0};
-    unsigned par = 0;    // bit i: direction component i is (nearly) zero
-    float dscale = 1.0f; // max(1, |direction|), rounded up: the culling margin grows with it
-    unsigned cur = 0;
-    double rec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int sp = 0;
-    bool flag = false, have_hit = false;
-    double best_t = 1e20, m2 = 0;
-    int best_pos = -1, best_rank = 0, best_list = -1, cur_list = -1;
-    // path bookkeeping: depth (bits 0-19), pending branches (20-22), sub-pixel (23-24), into (25), primary (26)
-    unsigned pst = 0;
-    int smp = 0;
-    unsigned outk = 0; // render: index of the pixel in the packed output; trace: index of the ray
-    Pending pend[MAX_SPLIT];
+    // both slots start as "nothing traced yet, needs work"
+#pragma unroll
+    for (int r = 0; r < RAYS_PER_LANE; r++) {
+        sH[lane + r * WAVE] = make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        S.lstate[LS_PST * lss + gslot0 + lane + r * WAVE] = 0.0;
+    }
+    unsigned kinds = K_SHADE | (K_SHADE << 4); // the kind of step each of the lane's two slots waits for
+    // work counters: wavefront-uniform ones count lanes by ballot; the own-list lengths are per lane
+    unsigned long long c_rays = 0, c_visits = 0, c_sphs = 0, c_shades = 0, c_done = 0, c_culls = 0, c_iters = 0, c_lanes = 0;
+    unsigned long long l_tris = 0;
 
     const d3 camo = ld3(cam.o), camd = ld3(cam.d), ccx = ld3(cam.cx), ccy = ld3(cam.cy);
     const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
 
     for (;;) {
-        // ---- vote: run the kind most lanes are waiting for
-        const int c0 = (int)__builtin_popcountll(__ballot(kind == K_NODE)), c1 = (int)__builtin_popcountll(__ballot(kind == K_CULL)),
-                  c2 = (int)__builtin_popcountll(__ballot(kind == K_TRI)), c3 = (int)__builtin_popcountll(__ballot(kind == K_SHADE));
+        // ---- vote: run the kind most lanes can serve
+        const unsigned k0 = kinds & 15u, k1 = kinds >> 4;
+        const unsigned km = (1u << k0) | (1u << k1);
+        const int c0 = __popcll(__ballot((km & (1u << K_NODE)) != 0)), c1 = __popcll(__ballot((km & (1u << K_CULL)) != 0)),
+                  c2 = __popcll(__ballot((km & (1u << K_TRI)) != 0)), c3 = __popcll(__ballot((km & (1u << K_SHADE)) != 0));
         int pick = K_NODE, most = c0;
         if (c1 > most) { most = c1; pick = K_CULL; }
         if (c2 > most) { most = c2; pick = K_TRI; }
         if (c3 > most) { most = c3; pick = K_SHADE; }
-        if (most == 0) break; // every lane is done
-        pick = __builtin_amdgcn_readfirstlane(pick);
-        const bool run = kind == pick;
-        if (lane == 0) { count(ST_ITERS, 1); count(ST_LANES, (unsigned)most); } // scheduler statistics, one lane per wavefront
+        if (most == 0) break; // every slot is done
+        const bool first = k0 == (unsigned)pick;
+        const bool run = (km >> pick) & 1u;
+        const int slot = first ? lane : lane + WAVE;
+        double *const ls = S.lstate + gslot0 + slot; // this slot's column of the HBM state
+        c_iters += 1;
+        c_lanes += (unsigned)most;
+
+        uint4 h = make_uint4(0u, 0u, 0u, 0u);
+        if (run) h = sH[slot];
+        const unsigned cur = h.x;
+        unsigned st = h.y;
+        int sp = (int)(st & ST_SP);
+        auto push = [&](unsigned item) __attribute__((always_inline)) {
+            if (sp < LDS_STACK) stk[sp][slot] = item;
+            else S.ovf[(size_t)(sp - LDS_STACK) * lss + gslot0 + slot] = item;
+            sp++;
+        };
         // what the step leaves behind for the common tail
         bool want_pop = false;  // take the next item from the stack (or finish the traversal)
         unsigned next = 0;      // otherwise: the item to continue with
         unsigned push_item = 0; // item to push before that (0 = none; the root is never pushed)
+        bool done = false;      // the slot found no more work
 
         if (pick == K_NODE) {
             if (run) { // ---- enter a node (kdtree.cpp:111-141)
-                const double mi[3] = {rec[0], rec[1], rec[2]}, ma[3] = {rec[3], rec[4], rec[5]};
-                const double split = rec[6];
-                const long long w7 = __double_as_longlong(rec[7]);
+                const double2 *p = (const double2 *)(S.pool + (size_t)cur * 16);
+                const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                const double v[3] = {ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]};
+                const double2 a = sA[slot], b = sB[slot], c = sC[slot], dd = sD[slot];
+                const double s[3] = {a.x, a.y, b.x}, inv[3] = {c.x, c.y, dd.x};
+                const double mi[3] = {q0.x, q0.y, q1.x}, ma[3] = {q1.y, q2.x, q2.y};
+                const double split = q3.x;
+                const long long w7 = __double_as_longlong(q3.y);
                 const unsigned right = (unsigned)w7, info = (unsigned)(w7 >> 32);
                 const unsigned node = cur;
-                count(ST_VISITS, 1);
                 // cheap necessary condition first: check_aabb can only accept a ray that meets the
                 // box grown by eps (plus rounding); clear misses skip the three divisions
                 const double pad = 2.5e-5 + 4e-12 * (fabs(s[0]) + fabs(s[1]) + fabs(s[2]) + fabs(mi[0]) + fabs(mi[1]) + fabs(mi[2]) +
                                                     fabs(ma[0]) + fabs(ma[1]) + fabs(ma[2]));
-                if (!slab_hit(mi, ma, pad, s, inv, par) || !aabb_hit(mi, ma, s, v)) want_pop = true;
+                if (!slab_hit(mi, ma, pad, s, inv) || !aabb_hit(mi, ma, s, v)) want_pop = true;
                 else {
-                    count(ST_TRIS, info >> 3); // the own list will be scanned (kdtree.cpp:122,131,137)
+                    l_tris += info >> 3; // the own list will be scanned (kdtree.cpp:122,131,137)
                     const int axis = info & 3;
                     const bool hasL = (info >> 2) & 1, hasR = right != 0;
                     const double sw = axis == 0 ? s[0] : axis == 1 ? s[1] : s[2];
@@ -421,93 +444,111 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                     }
                     // the own list and the far child come after the near subtree; the frame's flag
                     // travels in the item and the near subtree starts with a clean one
-                    const unsigned after = IT_AFTER | ((unsigned)flag << 30) | (farkind << 28) | node;
-                    flag = false;
+                    const unsigned after = IT_AFTER | (((st >> 8) & 1u) << 30) | (farkind << 28) | node;
+                    st &= ~ST_FLAG;
                     if (near != 0) { push_item = after; next = near; }
                     else next = after;
                 }
             }
+            c_visits += (unsigned)most;
         } else if (pick == K_CULL) {
+            bool boxes = false;
             if (run) { // ---- two child boxes of a list's hierarchy; for an after item, the list's start
-                const float2 f0 = __builtin_bit_cast(float2, rec[0]), f1 = __builtin_bit_cast(float2, rec[1]),
-                             f2 = __builtin_bit_cast(float2, rec[2]), f3 = __builtin_bit_cast(float2, rec[3]),
-                             f4 = __builtin_bit_cast(float2, rec[4]), f5 = __builtin_bit_cast(float2, rec[5]);
+                const unsigned g = (cur & IT_AFTER) ? (cur & IDX28) + 4u : (cur & IDX29);
+                const double2 *p = (const double2 *)(S.pool + (size_t)g * 16);
+                const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                const double2 a = sA[slot], b = sB[slot], c = sC[slot], dd = sD[slot];
+                const double s[3] = {a.x, a.y, b.x}, inv[3] = {c.x, c.y, dd.x};
+                const float2 md = __builtin_bit_cast(float2, dd.y); // list margin, the ray's margin factor
+                double m2 = (double)md.x;
+                const float2 f0 = __builtin_bit_cast(float2, q0.x), f1 = __builtin_bit_cast(float2, q0.y),
+                             f2 = __builtin_bit_cast(float2, q1.x), f3 = __builtin_bit_cast(float2, q1.y),
+                             f4 = __builtin_bit_cast(float2, q2.x), f5 = __builtin_bit_cast(float2, q2.y);
                 const double lo0[3] = {f0.x, f0.y, f1.x}, hi0[3] = {f1.y, f2.x, f2.y};
                 const double lo1[3] = {f3.x, f3.y, f4.x}, hi1[3] = {f4.y, f5.x, f5.y};
-                const long long w6 = __double_as_longlong(rec[6]);
-                const unsigned a = (unsigned)w6, b = (unsigned)(w6 >> 32);
-                bool boxes = true;
+                const long long w6 = __double_as_longlong(q3.x);
+                const unsigned ia = (unsigned)w6, ib = (unsigned)(w6 >> 32);
+                boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
-                    const long long w7 = __double_as_longlong(rec[7]);
+                    const long long w7 = __double_as_longlong(q3.y);
                     const unsigned right = (unsigned)w7, meta = (unsigned)(w7 >> 32);
                     const unsigned node = cur & IDX28, farkind = (cur >> 28) & 3;
-                    const bool near_hit = flag;          // what the near child's check() returned
-                    flag = ((cur >> 30) & 1) | near_hit; // back in the enclosing frame
-                    if (farkind != 0 && !near_hit) push(sp, farkind == 1 ? node + 8 : right); // kdtree.cpp:124,133: after the list
-                    cur_list = (int)node;
-                    if (meta & LIST_SHORT) { // up to SMALL_LIST triangles, in list order
+                    const bool near_hit = (st & ST_FLAG) != 0;         // what the near child's check() returned
+                    if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
+                    if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 8 : right); // kdtree.cpp:124,133: after the list
+                    sH[slot].z = node;                                   // the list now being scanned
+                    if (meta & LIST_SHORT) { // up to SMALL_LIST triangles: a chain of tri steps in list order
                         boxes = false;
-                        const int n = (int)(meta & 0xFF);
-                        if (n == 0) want_pop = true;
-                        else {
-                            for (int i = n - 1; i > 0; i--) push(sp, a + 5u * (unsigned)i);
-                            next = a;
-                        }
-                    } else { // margin of this list's boxes, see list_margin()
-                        const double lmax2 = (double)__uint_as_float(meta);
-                        double cx = 0.5 * (fmin(lo0[0], lo1[0]) + fmax(hi0[0], hi1[0])), ex = fmax(hi0[0], hi1[0]) - fmin(lo0[0], lo1[0]);
-                        double cy = 0.5 * (fmin(lo0[1], lo1[1]) + fmax(hi0[1], hi1[1])), ey = fmax(hi0[1], hi1[1]) - fmin(lo0[1], lo1[1]);
-                        double cz = 0.5 * (fmin(lo0[2], lo1[2]) + fmax(hi0[2], hi1[2])), ez = fmax(hi0[2], hi1[2]) - fmin(lo0[2], lo1[2]);
-                        const double r2 = 0.5 * sqrt(ex * ex + ey * ey + ez * ez) + sqrt(lmax2);
-                        m2 = 2.0 * (double)dscale * list_margin(cx, cy, cz, 1e-9 * lmax2 + 1e-10, r2, s);
+                        if ((meta & 0xFF) == 0) want_pop = true;
+                        else next = ia;
+                    } else { // inflation of this list's boxes, see ray_margin_factor(); a larger one only culls less
+                        const float m2f = __uint_as_float(meta) * md.y;
+                        m2 = (double)m2f;
+                        ((float *)&sD[slot])[2] = m2f;
                     }
                 }
                 if (boxes) {
-                    count(ST_CULLS, 1);
-                    const bool h0 = slab_hit(lo0, hi0, m2, s, inv, par), h1 = slab_hit(lo1, hi1, m2, s, inv, par);
-                    if (h0 && h1) { push_item = b; next = a; }
-                    else if (h0) next = a;
-                    else if (h1) next = b;
+                    const bool h0 = slab_hit(lo0, hi0, m2, s, inv), h1 = slab_hit(lo1, hi1, m2, s, inv);
+                    if (h0 && h1) { push_item = ib; next = ia; }
+                    else if (h0) next = ia;
+                    else if (h1) next = ib;
                     else want_pop = true;
                 }
             }
+            c_culls += (unsigned)__builtin_popcountll(__ballot(boxes));
         } else if (pick == K_TRI) {
             if (run) { // ---- one exact triangle test (kdtree.cpp:105)
-                const d3 o = mk(s[0], s[1], s[2]), d = mk(v[0], v[1], v[2]);
-                const double t = tri_hit(mk(rec[0], rec[1], rec[2]), mk(rec[3], rec[4], rec[5]), mk(rec[6], rec[7], rec[8]), o, d);
-                count(ST_DONE, 1);
+                const double2 *p = (const double2 *)(S.pool + (size_t)(cur & IDX28) * 16);
+                const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+                const long long w9 = __double_as_longlong(q4.y);
+                const d3 d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
+                const double2 a = sA[slot], b = sB[slot];
+                const uint2 gb = sG[slot];
+                const d3 o = mk(a.x, a.y, b.x);
+                const double best_t = b.y;
+                const double t = tri_hit(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d);
                 if (t > EPS) {
-                    const long long w9 = __double_as_longlong(rec[9]);
                     const int rk = (int)(w9 >> 32);
                     // strict < keeps the earlier of two equal distances; inside one list "earlier"
                     // is the lower rank, across lists it is the list visited first
-                    if (t < best_t || (t == best_t && best_list == cur_list && rk < best_rank)) {
-                        best_t = t; best_pos = (int)w9; best_rank = rk; best_list = cur_list;
+                    if (t < best_t || (t == best_t && gb.y == h.z && rk < (int)gb.x)) {
+                        sB[slot].y = t;
+                        sG[slot] = make_uint2((unsigned)rk, h.z);
+                        sH[slot].w = (unsigned)w9 & ~TRI_LAST;
                     }
-                    if (t < 1e10) flag = true;
+                    if (t < 1e10) st |= ST_FLAG;
                 }
-                want_pop = true;
+                if ((cur & IT_CHAIN) && !((unsigned)w9 & TRI_LAST)) next = cur + 5u; // the list's next triangle
+                else want_pop = true;
             }
+            c_done += (unsigned)most;
         } else {
+            bool ev_sph = false, ev_shade = false, ev_ray = false;
             if (run) { // ---- traversal finished (or nothing started yet)
                 bool go_on = false, need_primary = false, need_work = false;
                 d3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+                const unsigned long long wp = (unsigned long long)__double_as_longlong(ls[LS_PST * lss]);
+                const unsigned long long wo = (unsigned long long)__double_as_longlong(ls[LS_OUT * lss]);
+                const unsigned pst = (unsigned)wp;
+                int smp = (int)(wp >> 32);
+                unsigned outk = (unsigned)wo, pxy = (unsigned)(wo >> 32);
                 int depth = (int)(pst & 0xFFFFF), np = (int)((pst >> 20) & 7), sub = (int)((pst >> 23) & 3);
                 bool into = (pst >> 25) & 1, primary = (pst >> 26) & 1;
+                const bool have_hit = (pst >> 27) & 1;
                 unsigned long long rng = 0;
                 if (!TRACE) rng = (unsigned long long)__double_as_longlong(ls[LS_RNG * lss]);
                 if (have_hit) {
-                    have_hit = false;
-                    const d3 o = mk(s[0], s[1], s[2]), d = mk(v[0], v[1], v[2]);
+                    const double2 a = sA[slot], b = sB[slot];
+                    const d3 o = mk(a.x, a.y, b.x), d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
                     double ts;
                     int ids;
                     trace_spheres(S, o, d, ts, ids);
-                    count(ST_SPHS, (unsigned)S.n_sph);
-                    const double to = best_t;
-                    const int tpos = best_pos;
+                    ev_sph = true;
+                    const double to = b.y;
+                    const int tpos = (int)h.w;
                     const bool fo = to < 1e10, fs = ts < 1e10;
                     if (TRACE) {
-                        if (fo && !(ts < to)) count(ST_SHADES, 1);
+                        if (fo && !(ts < to)) ev_shade = true;
                         tri_id[outk] = fo ? S.tshade[tpos].gid : -1;
                         tri_t[outk] = to;
                         sph_id[outk] = fs ? ids : -1;
@@ -516,7 +557,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                     } else if (fo || fs) { // raytrace.cpp:48-67
                         d3 x, n, f, lig;
                         int type;
-                        d3 thr = ls_get3(LS_THR);
+                        d3 thr = mk(ls[LS_THR * lss], ls[(LS_THR + 1) * lss], ls[(LS_THR + 2) * lss]);
                         if (ts < to || !fo) {
                             const SphGeom g = S.sph[ids];
                             const SphShade sh = S.sshade[ids];
@@ -530,16 +571,18 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                             n = ld3(sh->nc);
                             f = ld3(sh->col); type = sh->type; lig = ld3(sh->lig);
                             if (primary && sub == 0 && smp == 0 && prim) prim[outk] = sh->gid;
-                            count(ST_SHADES, 1);
+                            ev_shade = true;
                         }
                         const d3 nl = dot(n, d) < 0 ? n : n * -1.0;
-                        if (lig.x != 0 || lig.y != 0 || lig.z != 0) ls_put3(LS_ACC, ls_get3(LS_ACC) + mult(thr, lig));
-                        const double p = f.x > f.y && f.x > f.z ? f.x : f.y > f.z ? f.y : f.z; // raytrace.cpp:69
+                        if (lig.x != 0 || lig.y != 0 || lig.z != 0) {
+                            ls[LS_ACC * lss] += thr.x * lig.x; ls[(LS_ACC + 1) * lss] += thr.y * lig.y; ls[(LS_ACC + 2) * lss] += thr.z * lig.z;
+                        }
+                        const double pm = f.x > f.y && f.x > f.z ? f.x : f.y > f.z ? f.y : f.z; // raytrace.cpp:69
                         ++depth;
                         go_on = true;
                         if (depth > P.hard_depth) go_on = false;
                         else if (depth > P.rr_depth) { // raytrace.cpp:70-74
-                            if (P.rr_mode && rng_next(rng) < p) f = f * (1 / p);
+                            if (P.rr_mode && rng_next(rng) < pm) f = f * (1 / pm);
                             else go_on = false;
                         }
                         if (go_on) {
@@ -561,50 +604,60 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                                 if (cos2t < 0) { ro = reflo; rd = refld; } // total internal reflection
                                 else {
                                     const d3 tdir = normv(d * nnt - n * ((into ? 1 : -1) * (ddn * nnt + sqrt(cos2t))));
-                                    const double a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(tdir, n));
-                                    const double Re = R0 + (1 - R0) * c * c * c * c * c, Tr = 1 - Re, Pp = .25 + .5 * Re, RP = Re / Pp,
+                                    const double a2 = nt - nc, b2 = nt + nc, R0 = a2 * a2 / (b2 * b2), c2 = 1 - (into ? -ddn : dot(tdir, n));
+                                    const double Re = R0 + (1 - R0) * c2 * c2 * c2 * c2 * c2, Tr = 1 - Re, Pp = .25 + .5 * Re, RP = Re / Pp,
                                                  TP = Tr / (1 - Pp);
                                     const d3 refro = x + d * EPS;
                                     if (depth > P.split_depth) {
                                         if (rng_next(rng) < Pp) { thr = thr * RP; ro = reflo; rd = refld; }
                                         else { thr = thr * TP; ro = refro; rd = tdir; into = !into; }
                                     } else { // both branches: park the reflection, follow the refraction first
-                                        Pending &q = pend[np++];
-                                        q.o = reflo; q.d = refld; q.thr = thr * Re; q.depth = depth; q.into = into;
+                                        double *q = ls + (size_t)(LS_PEND + PEND_WORDS * np) * lss;
+                                        np++;
+                                        const d3 pt = thr * Re;
+                                        q[0] = reflo.x; q[lss] = reflo.y; q[2 * lss] = reflo.z;
+                                        q[3 * lss] = refld.x; q[4 * lss] = refld.y; q[5 * lss] = refld.z;
+                                        q[6 * lss] = pt.x; q[7 * lss] = pt.y; q[8 * lss] = pt.z;
+                                        q[9 * lss] = __longlong_as_double((long long)((unsigned long long)(unsigned)depth | ((unsigned long long)into << 32)));
                                         thr = thr * Tr; ro = refro; rd = tdir; into = !into;
                                     }
                                 }
                             }
-                            ls_put3(LS_THR, thr);
+                            ls[LS_THR * lss] = thr.x; ls[(LS_THR + 1) * lss] = thr.y; ls[(LS_THR + 2) * lss] = thr.z;
                         }
                     } else if (primary && sub == 0 && smp == 0 && prim) prim[outk] = RT_ID_MISS;
                     primary = false;
                     if (!TRACE && !go_on) {
                         if (np > 0) { // resume a parked glass branch
-                            const Pending &q = pend[--np];
-                            ro = q.o; rd = q.d; ls_put3(LS_THR, q.thr); depth = q.depth; into = q.into != 0;
+                            --np;
+                            const double *q = ls + (size_t)(LS_PEND + PEND_WORDS * np) * lss;
+                            ro = mk(q[0], q[lss], q[2 * lss]); rd = mk(q[3 * lss], q[4 * lss], q[5 * lss]);
+                            ls[LS_THR * lss] = q[6 * lss]; ls[(LS_THR + 1) * lss] = q[7 * lss]; ls[(LS_THR + 2) * lss] = q[8 * lss];
+                            const unsigned long long w = (unsigned long long)__double_as_longlong(q[9 * lss]);
+                            depth = (int)(unsigned)w; into = (w >> 32) != 0;
                             go_on = true;
                         } else { // the path is complete (raytrace.cpp:203-205)
-                            d3 rsum = ls_get3(LS_RSUM) + ls_get3(LS_ACC) * (1.0 / samps);
+                            const double is = 1.0 / samps;
+                            d3 rsum = mk(ls[LS_RSUM * lss] + ls[LS_ACC * lss] * is, ls[(LS_RSUM + 1) * lss] + ls[(LS_ACC + 1) * lss] * is,
+                                         ls[(LS_RSUM + 2) * lss] + ls[(LS_ACC + 2) * lss] * is);
                             if (++smp == samps) {
                                 smp = 0;
-                                const d3 col = ls_get3(LS_COL) + mk(clamp01(rsum.x), clamp01(rsum.y), clamp01(rsum.z)) * .25;
+                                const d3 col = mk(ls[LS_COL * lss] + clamp01(rsum.x) * .25, ls[(LS_COL + 1) * lss] + clamp01(rsum.y) * .25,
+                                                  ls[(LS_COL + 2) * lss] + clamp01(rsum.z) * .25);
                                 rsum = mk(0, 0, 0);
                                 if (++sub == 4) {
                                     sub = 0;
                                     rgb[3 * (size_t)outk] = col.x; rgb[3 * (size_t)outk + 1] = col.y; rgb[3 * (size_t)outk + 2] = col.z;
                                     need_work = true;
-                                } else ls_put3(LS_COL, col);
+                                } else { ls[LS_COL * lss] = col.x; ls[(LS_COL + 1) * lss] = col.y; ls[(LS_COL + 2) * lss] = col.z; }
                             }
-                            ls_put3(LS_RSUM, rsum);
+                            ls[LS_RSUM * lss] = rsum.x; ls[(LS_RSUM + 1) * lss] = rsum.y; ls[(LS_RSUM + 2) * lss] = rsum.z;
                             need_primary = !need_work;
                         }
                     }
-                } else need_work = true; // first iteration: nothing traced yet
+                } else need_work = true; // first step of the slot: nothing traced yet
 
-                // ---- lanes without work take the next pixel (or ray) from the shared counter
-                unsigned pxy = 0;
-                if (!TRACE && need_primary) pxy = (unsigned)__double_as_longlong(ls[LS_PIX * lss]);
+                // ---- slots without work take the next pixel (or ray) from the shared counter
                 for (;;) {
                     const unsigned long long want = __ballot(need_work);
                     if (want == 0) break;
@@ -614,7 +667,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                     base = __shfl(base, leader, 64);
                     if (need_work) {
                         const unsigned w = base + (unsigned)__popcll(want & lane_lt);
-                        if (w >= n_work) { need_work = false; kind = K_DONE; }
+                        if (w >= n_work) { need_work = false; done = true; }
                         else if (TRACE) { outk = w; need_work = false; go_on = true; ro = ld3(rays + 6 * (size_t)w); rd = ld3(rays + 6 * (size_t)w + 3); }
                         else {
                             const unsigned blk = w >> 6, li = w & 63;
@@ -624,14 +677,14 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                                 if ((unsigned)tiles[mid].blk_first <= blk) lo = mid; else hi = mid - 1;
                             }
                             const DevTile T = tiles[lo];
-                            const int b = (int)blk - T.blk_first;
-                            const int lrow = (b / T.blk_cols) * 8 + (int)(li >> 3), lcol = (b % T.blk_cols) * 8 + (int)(li & 7);
+                            const int bq = (int)blk - T.blk_first;
+                            const int lrow = (bq / T.blk_cols) * 8 + (int)(li >> 3), lcol = (bq % T.blk_cols) * 8 + (int)(li & 7);
                             if (lrow < T.rows && lcol < T.cols) { // ragged edge blocks have unused lanes
                                 pxy = ((unsigned)(T.x0 + lrow) << 16) | (unsigned)(T.y0 + lcol);
-                                ls[LS_PIX * lss] = __longlong_as_double((long long)pxy);
                                 outk = (unsigned)(T.out_off + (long long)lrow * T.cols + lcol);
                                 sub = 0; smp = 0;
-                                ls_put3(LS_COL, mk(0, 0, 0)); ls_put3(LS_RSUM, mk(0, 0, 0));
+                                ls[LS_COL * lss] = 0; ls[(LS_COL + 1) * lss] = 0; ls[(LS_COL + 2) * lss] = 0;
+                                ls[LS_RSUM * lss] = 0; ls[(LS_RSUM + 1) * lss] = 0; ls[(LS_RSUM + 2) * lss] = 0;
                                 need_work = false;
                                 need_primary = true;
                             }
@@ -654,53 +707,63 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void k_main(DevScene S, DevCam
                     // (g++ evaluates the constructor arguments right to left)
                     rd = normv(dd);
                     ro = camo + rd * 140.0;
-                    ls_put3(LS_ACC, mk(0, 0, 0)); ls_put3(LS_THR, mk(1, 1, 1));
+                    ls[LS_ACC * lss] = 0; ls[(LS_ACC + 1) * lss] = 0; ls[(LS_ACC + 2) * lss] = 0;
+                    ls[LS_THR * lss] = 1; ls[(LS_THR + 1) * lss] = 1; ls[(LS_THR + 2) * lss] = 1;
                     depth = 0; into = true; np = 0; primary = true;
                     go_on = true;
                 }
                 if (!TRACE) ls[LS_RNG * lss] = __longlong_as_double((long long)rng);
-                pst = (unsigned)depth | ((unsigned)np << 20) | ((unsigned)sub << 23) | ((unsigned)into << 25) | ((unsigned)primary << 26);
+                const unsigned npst = (unsigned)depth | ((unsigned)np << 20) | ((unsigned)sub << 23) | ((unsigned)into << 25) |
+                                      ((unsigned)primary << 26) | ((unsigned)go_on << 27);
+                ls[LS_PST * lss] = __longlong_as_double((long long)((unsigned long long)npst | ((unsigned long long)(unsigned)smp << 32)));
+                ls[LS_OUT * lss] = __longlong_as_double((long long)((unsigned long long)outk | ((unsigned long long)pxy << 32)));
                 if (go_on) { // KdTree::check on the root (raytrace.cpp:46)
-                    s[0] = ro.x; s[1] = ro.y; s[2] = ro.z; v[0] = rd.x; v[1] = rd.y; v[2] = rd.z;
-                    par = (fabs(v[0]) < 1e-150 ? 1u : 0u) | (fabs(v[1]) < 1e-150 ? 2u : 0u) | (fabs(v[2]) < 1e-150 ? 4u : 0u);
-                    inv[0] = (par & 1) ? 0.0 : 1.0 / v[0]; inv[1] = (par & 2) ? 0.0 : 1.0 / v[1]; inv[2] = (par & 4) ? 0.0 : 1.0 / v[2];
-                    const float dl = (float)sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * 1.000001f;
-                    dscale = dl > 1.0f ? dl : 1.0f;
-                    best_t = 1e20; best_pos = -1; best_rank = 0; best_list = -1; cur_list = -1;
-                    sp = 0; flag = false;
-                    have_hit = true;
-                    count(ST_RAYS, 1);
+                    const double ix = fabs(rd.x) < 1e-150 ? 1e300 : 1.0 / rd.x, iy = fabs(rd.y) < 1e-150 ? 1e300 : 1.0 / rd.y,
+                                 iz = fabs(rd.z) < 1e-150 ? 1e300 : 1.0 / rd.z;
+                    float2 md;
+                    md.x = 0.0f;
+                    md.y = ray_margin_factor(S.cen, S.reach, S.absn, ro.x, ro.y, ro.z, sqrt(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z));
+                    sA[slot] = make_double2(ro.x, ro.y);
+                    sB[slot] = make_double2(ro.z, 1e20);
+                    sC[slot] = make_double2(ix, iy);
+                    sD[slot] = make_double2(iz, __builtin_bit_cast(double, md));
+                    sG[slot] = make_uint2(0u, 0xFFFFFFFFu);
+                    sH[slot].z = 0xFFFFFFFFu; sH[slot].w = 0xFFFFFFFFu;
+                    ls[LS_V * lss] = rd.x; ls[(LS_V + 1) * lss] = rd.y; ls[(LS_V + 2) * lss] = rd.z;
+                    st = 0;
+                    sp = 0;
+                    ev_ray = true;
                     // next stays 0: the root node
-                } else want_pop = true; // sp is 0: the lane stays idle (done, or out of work)
+                } else want_pop = true; // sp is 0: the slot stays idle (done, or out of work)
             }
+            c_sphs += (unsigned long long)(unsigned)S.n_sph * (unsigned)__builtin_popcountll(__ballot(ev_sph));
+            c_shades += (unsigned)__builtin_popcountll(__ballot(ev_shade));
+            c_rays += (unsigned)__builtin_popcountll(__ballot(ev_ray));
         }
 
-        // ---- common tail for the lanes that ran: push, pop, fetch the next item's record
+        // ---- common tail for the lanes that ran: push, pop, publish the slot's next item
         if (run) {
-            if (push_item != 0) push(sp, push_item);
+            if (push_item != 0) push(push_item);
             if (want_pop) {
-                if (sp == 0) next = 0xFFFFFFFFu; // the traversal is complete
+                if (sp == 0) next = IT_END;
                 else {
                     sp--;
-                    next = sp < LDS_STACK ? stk[sp][tid] : S.ovf[(size_t)(sp - LDS_STACK) * S.n_threads + gthread];
+                    next = sp < LDS_STACK ? stk[sp][slot] : S.ovf[(size_t)(sp - LDS_STACK) * lss + gslot0 + slot];
                 }
             }
-            if (kind != K_DONE) kind = next == 0xFFFFFFFFu ? K_SHADE : (next & IT_AFTER) ? K_CULL : (int)((next >> 29) & 3);
-            cur = next == 0xFFFFFFFFu ? 0u : next;
-            const unsigned g = (cur & IT_AFTER) ? (cur & IDX28) + 4u : (cur & IDX29);
-            const double2 *p = (const double2 *)(S.pool + (size_t)g * 16);
-            const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
-            rec[0] = q0.x; rec[1] = q0.y; rec[2] = q1.x; rec[3] = q1.y; rec[4] = q2.x; rec[5] = q2.y; rec[6] = q3.x; rec[7] = q3.y;
-            rec[8] = q4.x; rec[9] = q4.y;
+            const unsigned nk = done ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
+            *(uint2 *)&sH[slot] = make_uint2(next == IT_END ? 0u : next, (st & ~ST_SP) | (unsigned)sp);
+            kinds = first ? (kinds & ~15u) | nk : (kinds & 15u) | (nk << 4);
         }
     }
 
-    // ---- work counters: per-lane totals -> wavefront sum -> one atomic per counter
+    // ---- work counters: one atomic per counter and wavefront
+    for (int off = 32; off > 0; off >>= 1) l_tris += __shfl_down(l_tris, off, 64);
+    if (lane == 0) {
+        const unsigned long long tot[N_STATS] = {c_rays, c_visits, l_tris, c_sphs, c_shades, c_done, c_culls, c_iters, c_lanes};
 #pragma unroll
-    for (int k = 0; k < N_STATS; k++) {
-        unsigned long long x = sacc[k][tid];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane == 0 && x) atomicAdd(gstats + k, x);
+        for (int k = 0; k < N_STATS; k++)
+            if (tot[k]) atomicAdd(gstats + k, tot[k]);
     }
 }
 
@@ -838,9 +901,9 @@ void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &
     cull_split(B, 0, count, 1, li.lo0, li.hi0, li.lo1, li.hi1, li.a, li.b, lo, hi);
     max_depth = std::max(max_depth, B.max_depth);
     for (int j = 0; j < count; j++) order[first + j] = bt[j].src;
-    float l2f = f_up(lmax2); // the margin grows with it: round up
-    if (!(l2f >= 0.0f)) l2f = INFINITY;
-    memcpy(&li.meta, &l2f, 4);
+    float kf = f_up(2.0 * (1e-9 * lmax2 + 1e-10) * 1.000001); // the list's margin coefficient, rounded up
+    if (!(kf >= 0.0f)) kf = INFINITY;
+    memcpy(&li.meta, &kf, 4);
 }
 
 int validate(const rt_scene_desc *D) {
@@ -957,9 +1020,9 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     }
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, 16, stream));
     const DevCamera dc = make_camera(cam);
-    const int grid = (int)std::min<long long>(s->grid, (blocks + 3) / 4);
+    const int grid = (int)std::min<long long>(s->grid, (blocks + RAYS_PER_LANE - 1) / RAYS_PER_LANE);
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(k_main<false>, dim3(grid), dim3(BLOCK), 0, stream, s->d, dc, *p, (const DevTile *)s->d_tiles, n_tiles,
+    hipLaunchKernelGGL(k_main<false>, dim3(grid), dim3(WAVE), 0, stream, s->d, dc, *p, (const DevTile *)s->d_tiles, n_tiles,
                        (unsigned)(blocks * 64), s->d_counter, d_rgb, d_prim, (const double *)nullptr, (int *)nullptr,
                        (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats);
     HIP_TRY(hipGetLastError());
@@ -1009,7 +1072,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     for (int i = 0; i < D->n_nodes; i++)
         if (D->node_count[i] > SMALL_LIST) n_cull += (size_t)D->node_count[i] - 2; // inner records below the root
     const size_t g_cull = 8 * (size_t)D->n_nodes, g_tri = g_cull + 4 * n_cull, g_end = g_tri + 5 * (size_t)D->n_tris + 2;
-    if (g_cull > (size_t)IDX28 || g_end > (size_t)IDX29) return fail(RT_E_LIMIT, "scene too large for the 29-bit record index");
+    if (g_end > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
     std::vector<char> pool(g_end * 16, 0);
     std::vector<CullRec> cull;
     cull.reserve(n_cull);
@@ -1029,13 +1092,17 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         if (cnt > SMALL_LIST) build_list(D, first, cnt, order, cull, (unsigned)g_cull, (unsigned)g_tri, li, cull_depth);
         else {
             li.meta = LIST_SHORT | (unsigned)cnt;
-            li.a = IT_TRI | ((unsigned)g_tri + 5u * (unsigned)first);
+            li.a = IT_TRI | IT_CHAIN | ((unsigned)g_tri + 5u * (unsigned)first);
         }
         memcpy(&pool[(size_t)i * 128], &n, 64);
         memcpy(&pool[(size_t)i * 128 + 64], &li, 64);
     }
     if (cull.size() != n_cull) return fail(RT_E_INVALID, "internal: culling hierarchy size mismatch");
     if (n_cull) memcpy(&pool[g_cull * 16], cull.data(), n_cull * sizeof(CullRec));
+    std::vector<unsigned char> last((size_t)D->n_list, 0); // device position is the last of its own list
+    for (int i = 0; i < D->n_nodes; i++)
+        if (D->node_count[i] > 0) last[(size_t)D->node_first[i] + D->node_count[i] - 1] = 1;
+    double blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0}, lg2 = 0; // vertex box and longest edge of the scene
     std::vector<TriShade> tsh((size_t)D->n_tris);
     for (int pos = 0; pos < D->n_list; pos++) {
         const int rank = order[pos];
@@ -1047,7 +1114,15 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
             t.e1[k] = v[3 + k] - v[k]; // polygon.h:39
             t.e2[k] = v[6 + k] - v[k]; // polygon.h:40
         }
-        t.pos = pos;
+        for (int e = 0; e < 3; e++) {
+            const double *a = v + 3 * e, *b = v + 3 * ((e + 1) % 3);
+            lg2 = std::max(lg2, (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+            for (int k = 0; k < 3; k++) {
+                if (pos == 0 && e == 0) blo[k] = bhi[k] = a[k];
+                blo[k] = std::min(blo[k], a[k]); bhi[k] = std::max(bhi[k], a[k]);
+            }
+        }
+        t.pos = (int)((unsigned)pos | (last[pos] ? TRI_LAST : 0u));
         t.rank = rank;
         memcpy(&pool[(g_tri + 5 * (size_t)pos) * 16], &t, sizeof(t));
         TriShade &h = tsh[pos];
@@ -1083,16 +1158,20 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     hipDeviceProp_t pr;
     int per_cu = 0;
     if (hipGetDeviceProperties(&pr, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_main<false>, BLOCK, 0) != hipSuccess || per_cu < 1)
-        per_cu = 2;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_main<false>, WAVE, 0) != hipSuccess || per_cu < 1)
+        per_cu = 4;
     s->grid = pr.multiProcessorCount * per_cu;
-    const int n_threads = s->grid * BLOCK;
+    const int n_slots = s->grid * SLOTS;
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
     const int need_depth = D->tree_depth + cull_depth + SMALL_LIST + 3;
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK : 0;
+    if (need_depth > (int)ST_SP) { // the stack pointer is kept in 8 bits
+        rt_free_scene(s);
+        return fail(RT_E_LIMIT, "tree too deep: traversal stack of %d levels (max %u)", need_depth, ST_SP);
+    }
     hipError_t e = hipSuccess;
-    if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_threads * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc(&s->lstate, (size_t)LS_SLOTS * n_threads * sizeof(double));
+    if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_slots * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&s->lstate, (size_t)LS_WORDS * n_slots * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_counter, 16);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
@@ -1108,9 +1187,16 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->d.sshade = (const SphShade *)s->sshade;
     s->d.ovf = (unsigned *)s->ovf;
     s->d.lstate = (double *)s->lstate;
+    s->d.reach = std::sqrt(lg2) * 1.000001;
+    s->d.absn = 0;
+    for (int k = 0; k < 3; k++) {
+        s->d.cen[k] = 0.5 * (blo[k] + bhi[k]);
+        s->d.reach += 0.5 * (bhi[k] - blo[k]) * 1.000001;
+        s->d.absn += std::fabs(s->d.cen[k]) + 0.5 * (bhi[k] - blo[k]);
+    }
     s->d.n_sph = D->n_spheres;
     s->d.ovf_depth = ovf_depth;
-    s->d.n_threads = n_threads;
+    s->d.n_slots = n_slots;
     *out = s;
     return RT_OK;
 }
@@ -1203,11 +1289,11 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_counter, 0, 16);
     if (e == hipSuccess) {
-        const long long want = (n + BLOCK - 1) / BLOCK;
-        const int grid = (int)std::min<long long>(s->grid, want); // stay within the overflow stack's thread count
+        const long long want = (n + SLOTS - 1) / SLOTS;
+        const int grid = (int)std::min<long long>(s->grid, want); // stay within the slot count the state arrays were sized for
         rt_params none = {1, 0, 0, 0, 1, 0, 0};
         DevCamera nocam = {};
-        hipLaunchKernelGGL(k_main<true>, dim3(grid), dim3(BLOCK), 0, nullptr, s->d, nocam, none, (const DevTile *)nullptr, 0,
+        hipLaunchKernelGGL(k_main<true>, dim3(grid), dim3(WAVE), 0, nullptr, s->d, nocam, none, (const DevTile *)nullptr, 0,
                            (unsigned)n, s->d_counter, (double *)nullptr, (int *)nullptr, (const double *)d_rays, d_ti, d_tt, d_si,
                            d_st, s->d_stats);
         e = hipGetLastError();
