@@ -130,6 +130,7 @@ struct DevScene {
     double cen[3]; // centre of the scene's vertex box
     double reach;  // its summed half extents + the scene's longest triangle edge
     double absn;   // |centre|_1 + summed half extents
+    double padc;   // constant part of the node-box padding: 2.5e-5 + 4e-12 * (largest sum of |box coordinates| of a node)
     int n_sph;
     int ovf_depth;
     int n_slots;
@@ -351,34 +352,33 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     __shared__ double2 sB[SLOTS];       // origin z, best distance so far
     __shared__ double2 sC[SLOTS];       // 1/direction x, y
     __shared__ double2 sD[SLOTS];       // 1/direction z; float culling margin of the current list, float margin factor of the ray
-    __shared__ uint4 sH[SLOTS];         // current item, flags word, current list (node granule), best triangle (TriShade index)
-    __shared__ uint2 sG[SLOTS];         // best triangle's list rank, best triangle's list
+    __shared__ uint4 sH[SLOTS];         // current list (node granule); best triangle: TriShade index, list rank, list
     __shared__ unsigned stk[LDS_STACK][SLOTS];
     const int lane = threadIdx.x;
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const size_t lss = (size_t)S.n_slots;
-    const size_t gslot0 = (size_t)blockIdx.x * SLOTS;
+    const unsigned gslot0 = blockIdx.x * SLOTS;
 
     // both slots start as "nothing traced yet, needs work"
 #pragma unroll
-    for (int r = 0; r < RAYS_PER_LANE; r++) {
-        sH[lane + r * WAVE] = make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        S.lstate[LS_PST * lss + gslot0 + lane + r * WAVE] = 0.0;
-    }
-    unsigned kinds = K_SHADE | (K_SHADE << 4); // the kind of step each of the lane's two slots waits for
-    // work counters: wavefront-uniform ones count lanes by ballot; the own-list lengths are per lane
-    unsigned long long c_rays = 0, c_visits = 0, c_sphs = 0, c_shades = 0, c_done = 0, c_culls = 0, c_iters = 0, c_lanes = 0;
-    unsigned long long l_tris = 0;
+    for (int r = 0; r < RAYS_PER_LANE; r++) S.lstate[LS_PST * lss + gslot0 + lane + r * WAVE] = 0.0;
+    // the only per-ray state in registers: for each of the lane's two slots the kind of step it waits
+    // for (4 bits each), its current item and its flags word
+    unsigned kinds = K_SHADE | (K_SHADE << 4);
+    unsigned cur0 = 0, cur1 = 0, st0 = 0, st1 = 0;
+    // work counters, per lane: 32-bit in the traversal steps, folded into 64 bits at every shading step
+    unsigned h_iters = 0, h_ran = 0, h_visits = 0, h_culls = 0, h_done = 0, h_tris = 0;
+    unsigned long long t_iters = 0, t_ran = 0, t_visits = 0, t_culls = 0, t_done = 0, t_tris = 0, t_rays = 0, t_sphs = 0, t_shades = 0;
 
-    const d3 camo = ld3(cam.o), camd = ld3(cam.d), ccx = ld3(cam.cx), ccy = ld3(cam.cy);
     const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
 
     for (;;) {
         // ---- vote: run the kind most lanes can serve
         const unsigned k0 = kinds & 15u, k1 = kinds >> 4;
         const unsigned km = (1u << k0) | (1u << k1);
-        const int c0 = __popcll(__ballot((km & (1u << K_NODE)) != 0)), c1 = __popcll(__ballot((km & (1u << K_CULL)) != 0)),
-                  c2 = __popcll(__ballot((km & (1u << K_TRI)) != 0)), c3 = __popcll(__ballot((km & (1u << K_SHADE)) != 0));
+        int c0 = __popcll(__ballot((km & (1u << K_NODE)) != 0)), c1 = __popcll(__ballot((km & (1u << K_CULL)) != 0)),
+            c2 = __popcll(__ballot((km & (1u << K_TRI)) != 0)), c3 = __popcll(__ballot((km & (1u << K_SHADE)) != 0));
+        asm("" : "+s"(c0), "+s"(c1), "+s"(c2), "+s"(c3)); // keep the comparison below in 32-bit scalar registers
         int pick = K_NODE, most = c0;
         if (c1 > most) { most = c1; pick = K_CULL; }
         if (c2 > most) { most = c2; pick = K_TRI; }
@@ -388,17 +388,15 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         const bool run = (km >> pick) & 1u;
         const int slot = first ? lane : lane + WAVE;
         double *const ls = S.lstate + gslot0 + slot; // this slot's column of the HBM state
-        c_iters += 1;
-        c_lanes += (unsigned)most;
+        h_iters++;
+        if (run) h_ran++;
 
-        uint4 h = make_uint4(0u, 0u, 0u, 0u);
-        if (run) h = sH[slot];
-        const unsigned cur = h.x;
-        unsigned st = h.y;
+        const unsigned cur = first ? cur0 : cur1;
+        unsigned st = first ? st0 : st1;
         int sp = (int)(st & ST_SP);
         auto push = [&](unsigned item) __attribute__((always_inline)) {
             if (sp < LDS_STACK) stk[sp][slot] = item;
-            else S.ovf[(size_t)(sp - LDS_STACK) * lss + gslot0 + slot] = item;
+            else S.ovf[(unsigned)(sp - LDS_STACK) * (unsigned)S.n_slots + gslot0 + (unsigned)slot] = item;
             sp++;
         };
         // what the step leaves behind for the common tail
@@ -411,7 +409,6 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             if (run) { // ---- enter a node (kdtree.cpp:111-141)
                 const double2 *p = (const double2 *)(S.pool + (size_t)cur * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                const double v[3] = {ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]};
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot], dd = sD[slot];
                 const double s[3] = {a.x, a.y, b.x}, inv[3] = {c.x, c.y, dd.x};
                 const double mi[3] = {q0.x, q0.y, q1.x}, ma[3] = {q1.y, q2.x, q2.y};
@@ -419,29 +416,52 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const long long w7 = __double_as_longlong(q3.y);
                 const unsigned right = (unsigned)w7, info = (unsigned)(w7 >> 32);
                 const unsigned node = cur;
-                // cheap necessary condition first: check_aabb can only accept a ray that meets the
-                // box grown by eps (plus rounding); clear misses skip the three divisions
-                const double pad = 2.5e-5 + 4e-12 * (fabs(s[0]) + fabs(s[1]) + fabs(s[2]) + fabs(mi[0]) + fabs(mi[1]) + fabs(mi[2]) +
-                                                    fabs(ma[0]) + fabs(ma[1]) + fabs(ma[2]));
-                if (!slab_hit(mi, ma, pad, s, inv) || !aabb_hit(mi, ma, s, v)) want_pop = true;
-                else {
-                    l_tris += info >> 3; // the own list will be scanned (kdtree.cpp:122,131,137)
-                    const int axis = info & 3;
-                    const bool hasL = (info >> 2) & 1, hasR = right != 0;
-                    const double sw = axis == 0 ? s[0] : axis == 1 ? s[1] : s[2];
+                h_visits++;
+                // check_aabb (kdtree.h:57-76) is decided without its divisions whenever the answer is
+                // clear.  With the entry / exit parameters of the three slabs of the exact box:
+                //  * it can only accept a ray that meets the box grown by eps plus rounding (`pad`);
+                //  * it accepts an origin inside the box grown by eps (its own first test);
+                //  * it accepts a ray that enters the exact box at t > 2 eps through a face whose
+                //    direction component exceeds 2.5 eps: at the entry point the other two
+                //    coordinates are inside the box up to ~1e-9 (coordinates are bounded through
+                //    `pad`), far inside the eps tolerance of the reference's face test, so its
+                //    loop accepts on that axis.
+                // Whatever is left (grazing rays, nearly axis-parallel directions) runs the exact code.
+                const double pad = S.padc + 4e-12 * (fabs(s[0]) + fabs(s[1]) + fabs(s[2]));
+                double tin = -1e300, tout = 1e300, tinp = 0.0, toutp = 1e300, imax = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const double t1 = (mi[i] - s[i]) * inv[i], t2 = (ma[i] - s[i]) * inv[i];
+                    const double ta = fmin(t1, t2), tb = fmax(t1, t2), pi = pad * fabs(inv[i]);
+                    tin = fmax(tin, ta); tout = fmin(tout, tb);
+                    tinp = fmax(tinp, ta - pi); toutp = fmin(toutp, tb + pi);
+                    imax = fmax(imax, fabs(inv[i]));
+                }
+                const bool maybe = tinp <= toutp;
+                const bool inside = (mi[0] < s[0] + EPS) & (s[0] < ma[0] + EPS) & (mi[1] < s[1] + EPS) & (s[1] < ma[1] + EPS) &
+                                    (mi[2] < s[2] + EPS) & (s[2] < ma[2] + EPS);
+                const bool clear = (tin <= tout) & (tin > 2e-5) & (imax < 4e4) & (pad < 3e-5);
+                const int axis = info & 3;
+                const double sw = axis == 0 ? s[0] : axis == 1 ? s[1] : s[2];
+                const double iw = axis == 0 ? inv[0] : axis == 1 ? inv[1] : inv[2];
+                bool pass = maybe & (inside | clear);
+                bool vpos = iw > 0, vneg = iw < 0; // sign of the direction along the split axis
+                if ((maybe & !inside & !clear) | (fabs(iw) >= 1e299)) { // rare: needs the direction itself
+                    const double v[3] = {ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]};
+                    if (!pass) pass = maybe && aabb_hit(mi, ma, s, v);
                     const double vw = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
-                    unsigned near = 0, farkind = 0; // farkind 1: left child is the far one, 2: right child
-                    if (!hasL && !hasR) { /* leaf, or interior node whose triangles all straddle */ }
-                    else if (sw < split) { // kdtree.cpp:119-127
-                        if (hasL) near = node + 8;
-                        if (hasR && vw > 0) farkind = 2;
-                    } else if (sw > split) { // kdtree.cpp:128-136
-                        if (hasR) near = right;
-                        if (hasL && vw < 0) farkind = 1;
-                    } else { // kdtree.cpp:137-141: on the plane, only the child the ray points into
-                        if (vw < 0 && hasL) near = node + 8;
-                        else if (vw > 0 && hasR) near = right;
-                    }
+                    vpos = vw > 0; vneg = vw < 0;
+                }
+                if (!pass) want_pop = true;
+                else {
+                    h_tris += info >> 3; // the own list will be scanned (kdtree.cpp:122,131,137)
+                    const bool hasL = (info >> 2) & 1, hasR = right != 0;
+                    const bool lt = sw < split, gt = sw > split;
+                    // kdtree.cpp:119-127 (left of the plane), 128-136 (right of it), 137-141 (on it: only
+                    // the child the ray points into)
+                    const bool nearL = hasL & (lt | (!gt & vneg)), nearR = hasR & !nearL & (gt | (!lt & vpos));
+                    const unsigned near = nearL ? node + 8 : nearR ? right : 0u;
+                    const unsigned farkind = (lt & hasR & vpos) ? 2u : (gt & hasL & vneg) ? 1u : 0u; // 1: left child, 2: right child
                     // the own list and the far child come after the near subtree; the frame's flag
                     // travels in the item and the near subtree starts with a clean one
                     const unsigned after = IT_AFTER | (((st >> 8) & 1u) << 30) | (farkind << 28) | node;
@@ -450,9 +470,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     else next = after;
                 }
             }
-            c_visits += (unsigned)most;
         } else if (pick == K_CULL) {
-            bool boxes = false;
             if (run) { // ---- two child boxes of a list's hierarchy; for an after item, the list's start
                 const unsigned g = (cur & IT_AFTER) ? (cur & IDX28) + 4u : (cur & IDX29);
                 const double2 *p = (const double2 *)(S.pool + (size_t)g * 16);
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const double lo1[3] = {f3.x, f3.y, f4.x}, hi1[3] = {f4.y, f5.x, f5.y};
                 const long long w6 = __double_as_longlong(q3.x);
                 const unsigned ia = (unsigned)w6, ib = (unsigned)(w6 >> 32);
-                boxes = true;
+                bool boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
                     const long long w7 = __double_as_longlong(q3.y);
                     const unsigned right = (unsigned)w7, meta = (unsigned)(w7 >> 32);
@@ -476,7 +494,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const bool near_hit = (st & ST_FLAG) != 0;         // what the near child's check() returned
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
                     if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 8 : right); // kdtree.cpp:124,133: after the list
-                    sH[slot].z = node;                                   // the list now being scanned
+                    sH[slot].x = node;                                   // the list now being scanned
                     if (meta & LIST_SHORT) { // up to SMALL_LIST triangles: a chain of tri steps in list order
                         boxes = false;
                         if ((meta & 0xFF) == 0) want_pop = true;
@@ -488,6 +506,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     }
                 }
                 if (boxes) {
+                    h_culls++;
                     const bool h0 = slab_hit(lo0, hi0, m2, s, inv), h1 = slab_hit(lo1, hi1, m2, s, inv);
                     if (h0 && h1) { push_item = ib; next = ia; }
                     else if (h0) next = ia;
@@ -495,7 +514,6 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     else want_pop = true;
                 }
             }
-            c_culls += (unsigned)__builtin_popcountll(__ballot(boxes));
         } else if (pick == K_TRI) {
             if (run) { // ---- one exact triangle test (kdtree.cpp:105)
                 const double2 *p = (const double2 *)(S.pool + (size_t)(cur & IDX28) * 16);
@@ -503,28 +521,28 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const long long w9 = __double_as_longlong(q4.y);
                 const d3 d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
                 const double2 a = sA[slot], b = sB[slot];
-                const uint2 gb = sG[slot];
+                const uint4 h = sH[slot];
                 const d3 o = mk(a.x, a.y, b.x);
                 const double best_t = b.y;
                 const double t = tri_hit(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d);
+                h_done++;
                 if (t > EPS) {
                     const int rk = (int)(w9 >> 32);
                     // strict < keeps the earlier of two equal distances; inside one list "earlier"
                     // is the lower rank, across lists it is the list visited first
-                    if (t < best_t || (t == best_t && gb.y == h.z && rk < (int)gb.x)) {
+                    if (t < best_t || (t == best_t && h.w == h.x && rk < (int)h.z)) {
                         sB[slot].y = t;
-                        sG[slot] = make_uint2((unsigned)rk, h.z);
-                        sH[slot].w = (unsigned)w9 & ~TRI_LAST;
+                        sH[slot] = make_uint4(h.x, (unsigned)w9 & ~TRI_LAST, (unsigned)rk, h.x);
                     }
                     if (t < 1e10) st |= ST_FLAG;
                 }
                 if ((cur & IT_CHAIN) && !((unsigned)w9 & TRI_LAST)) next = cur + 5u; // the list's next triangle
                 else want_pop = true;
             }
-            c_done += (unsigned)most;
         } else {
-            bool ev_sph = false, ev_shade = false, ev_ray = false;
             if (run) { // ---- traversal finished (or nothing started yet)
+                t_iters += h_iters; t_ran += h_ran; t_visits += h_visits; t_culls += h_culls; t_done += h_done; t_tris += h_tris;
+                h_iters = h_ran = h_visits = h_culls = h_done = h_tris = 0;
                 bool go_on = false, need_primary = false, need_work = false;
                 d3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
                 const unsigned long long wp = (unsigned long long)__double_as_longlong(ls[LS_PST * lss]);
@@ -543,12 +561,12 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     double ts;
                     int ids;
                     trace_spheres(S, o, d, ts, ids);
-                    ev_sph = true;
+                    t_sphs += (unsigned)S.n_sph;
                     const double to = b.y;
-                    const int tpos = (int)h.w;
+                    const int tpos = (int)sH[slot].y;
                     const bool fo = to < 1e10, fs = ts < 1e10;
                     if (TRACE) {
-                        if (fo && !(ts < to)) ev_shade = true;
+                        if (fo && !(ts < to)) t_shades++;
                         tri_id[outk] = fo ? S.tshade[tpos].gid : -1;
                         tri_t[outk] = to;
                         sph_id[outk] = fs ? ids : -1;
@@ -571,7 +589,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                             n = ld3(sh->nc);
                             f = ld3(sh->col); type = sh->type; lig = ld3(sh->lig);
                             if (primary && sub == 0 && smp == 0 && prim) prim[outk] = sh->gid;
-                            ev_shade = true;
+                            t_shades++;
                         }
                         const d3 nl = dot(n, d) < 0 ? n : n * -1.0;
                         if (lig.x != 0 || lig.y != 0 || lig.z != 0) {
@@ -692,6 +710,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     }
                 }
                 if (!TRACE && need_primary) { // raytrace.cpp:196-203
+                    const d3 camo = ld3(cam.o), camd = ld3(cam.d), ccx = ld3(cam.cx), ccy = ld3(cam.cy);
                     const int sx = sub >> 1, sy = sub & 1, px = (int)(pxy >> 16), py = (int)(pxy & 0xFFFF);
                     const unsigned long long path =
                         ((((unsigned long long)px * (unsigned long long)sizey + (unsigned long long)py) * 2 + sx) * 2 + sy) *
@@ -727,18 +746,14 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     sB[slot] = make_double2(ro.z, 1e20);
                     sC[slot] = make_double2(ix, iy);
                     sD[slot] = make_double2(iz, __builtin_bit_cast(double, md));
-                    sG[slot] = make_uint2(0u, 0xFFFFFFFFu);
-                    sH[slot].z = 0xFFFFFFFFu; sH[slot].w = 0xFFFFFFFFu;
+                    sH[slot] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFEu);
                     ls[LS_V * lss] = rd.x; ls[(LS_V + 1) * lss] = rd.y; ls[(LS_V + 2) * lss] = rd.z;
                     st = 0;
                     sp = 0;
-                    ev_ray = true;
+                    t_rays++;
                     // next stays 0: the root node
                 } else want_pop = true; // sp is 0: the slot stays idle (done, or out of work)
             }
-            c_sphs += (unsigned long long)(unsigned)S.n_sph * (unsigned)__builtin_popcountll(__ballot(ev_sph));
-            c_shades += (unsigned)__builtin_popcountll(__ballot(ev_shade));
-            c_rays += (unsigned)__builtin_popcountll(__ballot(ev_ray));
         }
 
         // ---- common tail for the lanes that ran: push, pop, publish the slot's next item
@@ -748,19 +763,24 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 if (sp == 0) next = IT_END;
                 else {
                     sp--;
-                    next = sp < LDS_STACK ? stk[sp][slot] : S.ovf[(size_t)(sp - LDS_STACK) * lss + gslot0 + slot];
+                    next = sp < LDS_STACK ? stk[sp][slot] : S.ovf[(unsigned)(sp - LDS_STACK) * (unsigned)S.n_slots + gslot0 + (unsigned)slot];
                 }
             }
             const unsigned nk = done ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
-            *(uint2 *)&sH[slot] = make_uint2(next == IT_END ? 0u : next, (st & ~ST_SP) | (unsigned)sp);
-            kinds = first ? (kinds & ~15u) | nk : (kinds & 15u) | (nk << 4);
+            const unsigned ncur = next == IT_END ? 0u : next, nst = (st & ~ST_SP) | (unsigned)sp;
+            if (first) { cur0 = ncur; st0 = nst; kinds = (kinds & ~15u) | nk; }
+            else { cur1 = ncur; st1 = nst; kinds = (kinds & 15u) | (nk << 4); }
         }
     }
 
-    // ---- work counters: one atomic per counter and wavefront
-    for (int off = 32; off > 0; off >>= 1) l_tris += __shfl_down(l_tris, off, 64);
+    // ---- work counters: per-lane totals -> wavefront sum -> one atomic per counter
+    t_iters += h_iters; t_ran += h_ran; t_visits += h_visits; t_culls += h_culls; t_done += h_done; t_tris += h_tris;
+    unsigned long long tot[N_STATS] = {t_rays, t_visits, t_tris, t_sphs, t_shades, t_done, t_culls, 0, t_ran};
+#pragma unroll
+    for (int k = 0; k < N_STATS; k++)
+        for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_down(tot[k], off, 64);
+    tot[ST_ITERS] = t_iters; // the same in every lane
     if (lane == 0) {
-        const unsigned long long tot[N_STATS] = {c_rays, c_visits, l_tris, c_sphs, c_shades, c_done, c_culls, c_iters, c_lanes};
 #pragma unroll
         for (int k = 0; k < N_STATS; k++)
             if (tot[k]) atomicAdd(gstats + k, tot[k]);
@@ -1165,6 +1185,10 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
     const int need_depth = D->tree_depth + cull_depth + SMALL_LIST + 3;
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK : 0;
+    if ((long long)ovf_depth * n_slots >= (1ll << 31)) {
+        rt_free_scene(s);
+        return fail(RT_E_LIMIT, "overflow stack of %d levels x %d slots exceeds the 31-bit index", ovf_depth, n_slots);
+    }
     if (need_depth > (int)ST_SP) { // the stack pointer is kept in 8 bits
         rt_free_scene(s);
         return fail(RT_E_LIMIT, "tree too deep: traversal stack of %d levels (max %u)", need_depth, ST_SP);
@@ -1194,6 +1218,13 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         s->d.reach += 0.5 * (bhi[k] - blo[k]) * 1.000001;
         s->d.absn += std::fabs(s->d.cen[k]) + 0.5 * (bhi[k] - blo[k]);
     }
+    double boxsum = 0;
+    for (int i = 0; i < D->n_nodes; i++) {
+        double b = 0;
+        for (int k = 0; k < 6; k++) b += std::fabs(D->node_box[6 * (size_t)i + k]);
+        if (!(b <= boxsum)) boxsum = b; // also takes a NaN, which then disables the shortcut
+    }
+    s->d.padc = 2.5e-5 + 4e-12 * boxsum;
     s->d.n_sph = D->n_spheres;
     s->d.ovf_depth = ovf_depth;
     s->d.n_slots = n_slots;
