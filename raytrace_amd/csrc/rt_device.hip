@@ -127,6 +127,7 @@ struct DevScene {
     const SphShade *sshade;
     unsigned *ovf;  // overflow stack [ovf_depth][n_slots]
     double *lstate; // per-slot state kept in HBM [LS_WORDS][n_slots]
+    unsigned long long *tstat; // per-lane 64-bit work counter totals [N_LCNT][threads]
     double cen[3]; // centre of the scene's vertex box
     double reach;  // its summed half extents + the scene's longest triangle edge
     double absn;   // |centre|_1 + summed half extents
@@ -311,6 +312,7 @@ constexpr unsigned TRI_LAST = 0x80000000u; // in TriRec::pos: last triangle of i
 constexpr unsigned IT_END = 0xFFFFFFFFu; // "the stack is empty": the traversal is complete
 enum { K_NODE = 0, K_CULL = 1, K_TRI = 2, K_SHADE = 3, K_DONE = 4 };
 enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, ST_ITERS, ST_LANES };
+enum { LC_RAYS = 0, LC_VISITS, LC_TRIS, LC_SHADES, LC_DONE, LC_CULLS, N_LCNT }; // the counters kept per lane
 // Words of a ray slot's state kept in HBM (8 bytes each, [word][slot] so lanes coalesce): what
 // only the shading step touches, plus the ray direction (read together with a record).
 //   LS_PST  low: depth (bits 0-19), pending branches (20-22), sub-pixel (23-24), into (25),
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     __shared__ double2 sD[SLOTS];       // 1/direction z; float culling margin of the current list, float margin factor of the ray
     __shared__ uint4 sH[SLOTS];         // current list (node granule); best triangle: TriShade index, list rank, list
     __shared__ unsigned stk[LDS_STACK][SLOTS];
+    __shared__ unsigned scnt[N_LCNT][WAVE]; // per-lane work counters, see count()
     const int lane = threadIdx.x;
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const size_t lss = (size_t)S.n_slots;
@@ -366,9 +369,25 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     // for (4 bits each), its current item and its flags word
     unsigned kinds = K_SHADE | (K_SHADE << 4);
     unsigned cur0 = 0, cur1 = 0, st0 = 0, st1 = 0;
-    // work counters, per lane: 32-bit in the traversal steps, folded into 64 bits at every shading step
-    unsigned h_iters = 0, h_ran = 0, h_visits = 0, h_culls = 0, h_done = 0, h_tris = 0;
-    unsigned long long t_iters = 0, t_ran = 0, t_visits = 0, t_culls = 0, t_done = 0, t_tris = 0, t_rays = 0, t_sphs = 0, t_shades = 0;
+    // work counters: per lane, 32 bits, in LDS (one LDS add per event, no registers held across
+    // the loop); a lane moves them to its 64-bit totals in HBM before they can overflow.  The
+    // scheduler's own two counters are wavefront-uniform.
+#pragma unroll
+    for (int k = 0; k < N_LCNT; k++) {
+        scnt[k][lane] = 0;
+        S.tstat[(size_t)k * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane] = 0;
+    }
+    auto count = [&](int k, unsigned n) __attribute__((always_inline)) {
+        __hip_atomic_fetch_add(&scnt[k][lane], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    auto fold = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < N_LCNT; k++) {
+            S.tstat[(size_t)k * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane] += scnt[k][lane];
+            scnt[k][lane] = 0;
+        }
+    };
+    unsigned long long c_iters = 0, c_lanes = 0;
 
     const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
 
@@ -388,8 +407,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         const bool run = (km >> pick) & 1u;
         const int slot = first ? lane : lane + WAVE;
         double *const ls = S.lstate + gslot0 + slot; // this slot's column of the HBM state
-        h_iters++;
-        if (run) h_ran++;
+        c_iters += 1;
+        c_lanes += (unsigned)most;
 
         const unsigned cur = first ? cur0 : cur1;
         unsigned st = first ? st0 : st1;
@@ -416,7 +435,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const long long w7 = __double_as_longlong(q3.y);
                 const unsigned right = (unsigned)w7, info = (unsigned)(w7 >> 32);
                 const unsigned node = cur;
-                h_visits++;
+                count(LC_VISITS, 1);
                 // check_aabb (kdtree.h:57-76) is decided without its divisions whenever the answer is
                 // clear.  With the entry / exit parameters of the three slabs of the exact box:
                 //  * it can only accept a ray that meets the box grown by eps plus rounding (`pad`);
@@ -454,7 +473,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 }
                 if (!pass) want_pop = true;
                 else {
-                    h_tris += info >> 3; // the own list will be scanned (kdtree.cpp:122,131,137)
+                    count(LC_TRIS, info >> 3); // the own list will be scanned (kdtree.cpp:122,131,137)
                     const bool hasL = (info >> 2) & 1, hasR = right != 0;
                     const bool lt = sw < split, gt = sw > split;
                     // kdtree.cpp:119-127 (left of the plane), 128-136 (right of it), 137-141 (on it: only
@@ -506,7 +525,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     }
                 }
                 if (boxes) {
-                    h_culls++;
+                    count(LC_CULLS, 1);
                     const bool h0 = slab_hit(lo0, hi0, m2, s, inv), h1 = slab_hit(lo1, hi1, m2, s, inv);
                     if (h0 && h1) { push_item = ib; next = ia; }
                     else if (h0) next = ia;
@@ -525,7 +544,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const d3 o = mk(a.x, a.y, b.x);
                 const double best_t = b.y;
                 const double t = tri_hit(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d);
-                h_done++;
+                count(LC_DONE, 1);
                 if (t > EPS) {
                     const int rk = (int)(w9 >> 32);
                     // strict < keeps the earlier of two equal distances; inside one list "earlier"
@@ -541,8 +560,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             }
         } else {
             if (run) { // ---- traversal finished (or nothing started yet)
-                t_iters += h_iters; t_ran += h_ran; t_visits += h_visits; t_culls += h_culls; t_done += h_done; t_tris += h_tris;
-                h_iters = h_ran = h_visits = h_culls = h_done = h_tris = 0;
+                if ((scnt[LC_TRIS][lane] | scnt[LC_VISITS][lane] | scnt[LC_CULLS][lane] | scnt[LC_DONE][lane] | scnt[LC_RAYS][lane]) >> 30) fold();
                 bool go_on = false, need_primary = false, need_work = false;
                 d3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
                 const unsigned long long wp = (unsigned long long)__double_as_longlong(ls[LS_PST * lss]);
@@ -561,12 +579,11 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     double ts;
                     int ids;
                     trace_spheres(S, o, d, ts, ids);
-                    t_sphs += (unsigned)S.n_sph;
                     const double to = b.y;
                     const int tpos = (int)sH[slot].y;
                     const bool fo = to < 1e10, fs = ts < 1e10;
                     if (TRACE) {
-                        if (fo && !(ts < to)) t_shades++;
+                        if (fo && !(ts < to)) count(LC_SHADES, 1);
                         tri_id[outk] = fo ? S.tshade[tpos].gid : -1;
                         tri_t[outk] = to;
                         sph_id[outk] = fs ? ids : -1;
@@ -589,7 +606,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                             n = ld3(sh->nc);
                             f = ld3(sh->col); type = sh->type; lig = ld3(sh->lig);
                             if (primary && sub == 0 && smp == 0 && prim) prim[outk] = sh->gid;
-                            t_shades++;
+                            count(LC_SHADES, 1);
                         }
                         const d3 nl = dot(n, d) < 0 ? n : n * -1.0;
                         if (lig.x != 0 || lig.y != 0 || lig.z != 0) {
@@ -750,7 +767,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     ls[LS_V * lss] = rd.x; ls[(LS_V + 1) * lss] = rd.y; ls[(LS_V + 2) * lss] = rd.z;
                     st = 0;
                     sp = 0;
-                    t_rays++;
+                    count(LC_RAYS, 1);
                     // next stays 0: the root node
                 } else want_pop = true; // sp is 0: the slot stays idle (done, or out of work)
             }
@@ -774,12 +791,22 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     }
 
     // ---- work counters: per-lane totals -> wavefront sum -> one atomic per counter
-    t_iters += h_iters; t_ran += h_ran; t_visits += h_visits; t_culls += h_culls; t_done += h_done; t_tris += h_tris;
-    unsigned long long tot[N_STATS] = {t_rays, t_visits, t_tris, t_sphs, t_shades, t_done, t_culls, 0, t_ran};
+    fold();
+    unsigned long long tot[N_STATS];
+#pragma unroll
+    for (int k = 0; k < N_STATS; k++) tot[k] = 0;
+    tot[ST_RAYS] = S.tstat[(size_t)LC_RAYS * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
+    tot[ST_VISITS] = S.tstat[(size_t)LC_VISITS * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
+    tot[ST_TRIS] = S.tstat[(size_t)LC_TRIS * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
+    tot[ST_SHADES] = S.tstat[(size_t)LC_SHADES * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
+    tot[ST_DONE] = S.tstat[(size_t)LC_DONE * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
+    tot[ST_CULLS] = S.tstat[(size_t)LC_CULLS * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
+    tot[ST_SPHS] = tot[ST_RAYS] * (unsigned)S.n_sph; // every traced ray scans all spheres (sphere.cpp:3-14)
 #pragma unroll
     for (int k = 0; k < N_STATS; k++)
         for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_down(tot[k], off, 64);
-    tot[ST_ITERS] = t_iters; // the same in every lane
+    tot[ST_ITERS] = c_iters;
+    tot[ST_LANES] = c_lanes;
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < N_STATS; k++)
@@ -819,7 +846,7 @@ struct rt_scene {
     int dev = 0;
     DevScene d{};
     void *pool = nullptr, *tshade = nullptr, *sph = nullptr, *sshade = nullptr;
-    void *ovf = nullptr, *lstate = nullptr;
+    void *ovf = nullptr, *lstate = nullptr, *tstat = nullptr;
     int tree_depth = 0;
     int grid = 0;               // persistent workgroups
     unsigned *d_counter = nullptr; // [0] block counter
@@ -1196,6 +1223,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     hipError_t e = hipSuccess;
     if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_slots * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&s->lstate, (size_t)LS_WORDS * n_slots * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&s->tstat, (size_t)6 * s->grid * WAVE * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_counter, 16);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
@@ -1211,6 +1239,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->d.sshade = (const SphShade *)s->sshade;
     s->d.ovf = (unsigned *)s->ovf;
     s->d.lstate = (double *)s->lstate;
+    s->d.tstat = (unsigned long long *)s->tstat;
     s->d.reach = std::sqrt(lg2) * 1.000001;
     s->d.absn = 0;
     for (int k = 0; k < 3; k++) {
@@ -1235,7 +1264,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->d_counter, s->d_stats, s->d_tiles};
+    void *ptrs[] = {s->pool, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->tstat, s->d_counter, s->d_stats, s->d_tiles};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
