@@ -57,14 +57,14 @@
 namespace {
 
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 2 // wavefronts per SIMD the register allocation is bounded for
+#define RT_MIN_WAVES 3 // wavefronts per SIMD the register allocation is bounded for
 #endif
 
 constexpr double EPS = 1e-5;  // point.h:7
 constexpr int WAVE = 64;          // threads per workgroup: one wavefront
 constexpr int RAYS_PER_LANE = 2;  // ray slots each lane chooses from
 constexpr int SLOTS = WAVE * RAYS_PER_LANE; // ray slots per workgroup
-constexpr int LDS_STACK = 16;     // traversal-stack levels kept in LDS
+constexpr int LDS_STACK = 14;     // traversal-stack levels kept in LDS
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 constexpr int N_STATS = 9;
 constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly, longer ones get a hierarchy
@@ -127,7 +127,6 @@ struct DevScene {
     const SphShade *sshade;
     unsigned *ovf;  // overflow stack [ovf_depth][n_slots]
     double *lstate; // per-slot state kept in HBM [LS_WORDS][n_slots]
-    unsigned long long *tstat; // per-lane 64-bit work counter totals [N_LCNT][threads]
     double cen[3]; // centre of the scene's vertex box
     double reach;  // its summed half extents + the scene's longest triangle edge
     double absn;   // |centre|_1 + summed half extents
@@ -312,14 +311,18 @@ constexpr unsigned TRI_LAST = 0x80000000u; // in TriRec::pos: last triangle of i
 constexpr unsigned IT_END = 0xFFFFFFFFu; // "the stack is empty": the traversal is complete
 enum { K_NODE = 0, K_CULL = 1, K_TRI = 2, K_SHADE = 3, K_DONE = 4 };
 enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, ST_ITERS, ST_LANES };
-enum { LC_RAYS = 0, LC_VISITS, LC_TRIS, LC_SHADES, LC_DONE, LC_CULLS, N_LCNT }; // the counters kept per lane
 // Words of a ray slot's state kept in HBM (8 bytes each, [word][slot] so lanes coalesce): what
 // only the shading step touches, plus the ray direction (read together with a record).
 //   LS_PST  low: depth (bits 0-19), pending branches (20-22), sub-pixel (23-24), into (25),
 //           primary (26), a traversal is waiting to be shaded (27); high: sample index
 //   LS_OUT  low: index in the packed output (render) / ray index (trace); high: pixel x << 16 | y
 //   LS_PEND parked glass branches, PEND_WORDS each: origin, direction, throughput, depth | into << 32
-enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13, LS_OUT = 14, LS_V = 15, LS_PEND = 18 };
+//   LS_V    ray direction;  LS_BT best distance so far
+//   LS_HA   low: current list (node granule); high: best triangle (TriShade index)
+//   LS_HB   best triangle's list rank (low) and list (high)
+//   LS_G    low: the ray's margin factor (float)
+enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13, LS_OUT = 14, LS_V = 15, LS_BT = 18, LS_HA = 19,
+       LS_HB = 20, LS_G = 21, LS_PEND = 22 };
 constexpr int PEND_WORDS = 10;
 constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
 // per-slot flags word in LDS: stack pointer (bits 0-7), the frame's "has a hit" flag (8)
@@ -350,13 +353,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                                                              unsigned n_work, unsigned *counter, double *rgb, int *prim,
                                                              const double *rays, int *tri_id, double *tri_t, int *sph_id,
                                                              double *sph_t, unsigned long long *gstats) {
-    __shared__ double2 sA[SLOTS];       // origin x, y
-    __shared__ double2 sB[SLOTS];       // origin z, best distance so far
-    __shared__ double2 sC[SLOTS];       // 1/direction x, y
-    __shared__ double2 sD[SLOTS];       // 1/direction z; float culling margin of the current list, float margin factor of the ray
-    __shared__ uint4 sH[SLOTS];         // current list (node granule); best triangle: TriShade index, list rank, list
+    __shared__ double2 sA[SLOTS]; // origin x, y
+    __shared__ double2 sB[SLOTS]; // origin z, 1/direction x
+    __shared__ double2 sC[SLOTS]; // 1/direction y, z
     __shared__ unsigned stk[LDS_STACK][SLOTS];
-    __shared__ unsigned scnt[N_LCNT][WAVE]; // per-lane work counters, see count()
     const int lane = threadIdx.x;
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const size_t lss = (size_t)S.n_slots;
@@ -366,28 +366,28 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
 #pragma unroll
     for (int r = 0; r < RAYS_PER_LANE; r++) S.lstate[LS_PST * lss + gslot0 + lane + r * WAVE] = 0.0;
     // the only per-ray state in registers: for each of the lane's two slots the kind of step it waits
-    // for (4 bits each), its current item and its flags word
+    // for (4 bits each), its current item, its flags word and the inflation of its current list's boxes
     unsigned kinds = K_SHADE | (K_SHADE << 4);
     unsigned cur0 = 0, cur1 = 0, st0 = 0, st1 = 0;
-    // work counters: per lane, 32 bits, in LDS (one LDS add per event, no registers held across
-    // the loop); a lane moves them to its 64-bit totals in HBM before they can overflow.  The
-    // scheduler's own two counters are wavefront-uniform.
-#pragma unroll
-    for (int k = 0; k < N_LCNT; k++) {
-        scnt[k][lane] = 0;
-        S.tstat[(size_t)k * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane] = 0;
-    }
-    auto count = [&](int k, unsigned n) __attribute__((always_inline)) {
-        __hip_atomic_fetch_add(&scnt[k][lane], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    };
-    auto fold = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < N_LCNT; k++) {
-            S.tstat[(size_t)k * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane] += scnt[k][lane];
-            scnt[k][lane] = 0;
+    float mg0 = 0.0f, mg1 = 0.0f;
+    // work counters: wavefront-uniform 32-bit sums of lane counts in scalar registers, flushed to
+    // the 64-bit totals in HBM long before they can overflow; only the own-list lengths need a
+    // per-lane sum
+    unsigned c_rays = 0, c_visits = 0, c_shades = 0, c_done = 0, c_culls = 0, c_iters = 0, c_lanes = 0;
+    unsigned long long l_tris = 0;
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (lane == 0) {
+            if (c_rays) { atomicAdd(gstats + ST_RAYS, (unsigned long long)c_rays); atomicAdd(gstats + ST_SPHS, (unsigned long long)c_rays * (unsigned)S.n_sph); }
+            if (c_visits) atomicAdd(gstats + ST_VISITS, (unsigned long long)c_visits);
+            if (c_shades) atomicAdd(gstats + ST_SHADES, (unsigned long long)c_shades);
+            if (c_done) atomicAdd(gstats + ST_DONE, (unsigned long long)c_done);
+            if (c_culls) atomicAdd(gstats + ST_CULLS, (unsigned long long)c_culls);
+            atomicAdd(gstats + ST_ITERS, (unsigned long long)c_iters);
+            atomicAdd(gstats + ST_LANES, (unsigned long long)c_lanes);
         }
+        c_rays = c_visits = c_shades = c_done = c_culls = c_iters = c_lanes = 0;
     };
-    unsigned long long c_iters = 0, c_lanes = 0;
+#define RT_SCOUNT(c, n) (c) += (unsigned)(n)
 
     const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
 
@@ -407,8 +407,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         const bool run = (km >> pick) & 1u;
         const int slot = first ? lane : lane + WAVE;
         double *const ls = S.lstate + gslot0 + slot; // this slot's column of the HBM state
-        c_iters += 1;
-        c_lanes += (unsigned)most;
+        RT_SCOUNT(c_iters, 1);
+        RT_SCOUNT(c_lanes, most);
 
         const unsigned cur = first ? cur0 : cur1;
         unsigned st = first ? st0 : st1;
@@ -428,14 +428,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             if (run) { // ---- enter a node (kdtree.cpp:111-141)
                 const double2 *p = (const double2 *)(S.pool + (size_t)cur * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                const double2 a = sA[slot], b = sB[slot], c = sC[slot], dd = sD[slot];
-                const double s[3] = {a.x, a.y, b.x}, inv[3] = {c.x, c.y, dd.x};
+                const double2 a = sA[slot], b = sB[slot], c = sC[slot];
+                const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
                 const double mi[3] = {q0.x, q0.y, q1.x}, ma[3] = {q1.y, q2.x, q2.y};
                 const double split = q3.x;
                 const long long w7 = __double_as_longlong(q3.y);
                 const unsigned right = (unsigned)w7, info = (unsigned)(w7 >> 32);
                 const unsigned node = cur;
-                count(LC_VISITS, 1);
                 // check_aabb (kdtree.h:57-76) is decided without its divisions whenever the answer is
                 // clear.  With the entry / exit parameters of the three slabs of the exact box:
                 //  * it can only accept a ray that meets the box grown by eps plus rounding (`pad`);
@@ -473,7 +472,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 }
                 if (!pass) want_pop = true;
                 else {
-                    count(LC_TRIS, info >> 3); // the own list will be scanned (kdtree.cpp:122,131,137)
+                    l_tris += info >> 3; // the own list will be scanned (kdtree.cpp:122,131,137)
                     const bool hasL = (info >> 2) & 1, hasR = right != 0;
                     const bool lt = sw < split, gt = sw > split;
                     // kdtree.cpp:119-127 (left of the plane), 128-136 (right of it), 137-141 (on it: only
@@ -489,15 +488,17 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     else next = after;
                 }
             }
+            RT_SCOUNT(c_visits, most);
         } else if (pick == K_CULL) {
+            bool boxes = false;
             if (run) { // ---- two child boxes of a list's hierarchy; for an after item, the list's start
                 const unsigned g = (cur & IT_AFTER) ? (cur & IDX28) + 4u : (cur & IDX29);
                 const double2 *p = (const double2 *)(S.pool + (size_t)g * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                const double2 a = sA[slot], b = sB[slot], c = sC[slot], dd = sD[slot];
-                const double s[3] = {a.x, a.y, b.x}, inv[3] = {c.x, c.y, dd.x};
-                const float2 md = __builtin_bit_cast(float2, dd.y); // list margin, the ray's margin factor
-                double m2 = (double)md.x;
+                const unsigned gw = ((const unsigned *)&ls[LS_G * lss])[0]; // the ray's margin factor, for a list's first step
+                const double2 a = sA[slot], b = sB[slot], c = sC[slot];
+                const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
+                float mg = first ? mg0 : mg1;
                 const float2 f0 = __builtin_bit_cast(float2, q0.x), f1 = __builtin_bit_cast(float2, q0.y),
                              f2 = __builtin_bit_cast(float2, q1.x), f3 = __builtin_bit_cast(float2, q1.y),
                              f4 = __builtin_bit_cast(float2, q2.x), f5 = __builtin_bit_cast(float2, q2.y);
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const double lo1[3] = {f3.x, f3.y, f4.x}, hi1[3] = {f4.y, f5.x, f5.y};
                 const long long w6 = __double_as_longlong(q3.x);
                 const unsigned ia = (unsigned)w6, ib = (unsigned)(w6 >> 32);
-                bool boxes = true;
+                boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
                     const long long w7 = __double_as_longlong(q3.y);
                     const unsigned right = (unsigned)w7, meta = (unsigned)(w7 >> 32);
@@ -513,19 +514,18 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const bool near_hit = (st & ST_FLAG) != 0;         // what the near child's check() returned
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
                     if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 8 : right); // kdtree.cpp:124,133: after the list
-                    sH[slot].x = node;                                   // the list now being scanned
+                    ((unsigned *)&ls[LS_HA * lss])[0] = node;            // the list now being scanned
                     if (meta & LIST_SHORT) { // up to SMALL_LIST triangles: a chain of tri steps in list order
                         boxes = false;
                         if ((meta & 0xFF) == 0) want_pop = true;
                         else next = ia;
                     } else { // inflation of this list's boxes, see ray_margin_factor(); a larger one only culls less
-                        const float m2f = __uint_as_float(meta) * md.y;
-                        m2 = (double)m2f;
-                        ((float *)&sD[slot])[2] = m2f;
+                        mg = __uint_as_float(meta) * __uint_as_float(gw);
+                        if (first) mg0 = mg; else mg1 = mg;
                     }
                 }
                 if (boxes) {
-                    count(LC_CULLS, 1);
+                    const double m2 = (double)mg;
                     const bool h0 = slab_hit(lo0, hi0, m2, s, inv), h1 = slab_hit(lo1, hi1, m2, s, inv);
                     if (h0 && h1) { push_item = ib; next = ia; }
                     else if (h0) next = ia;
@@ -533,34 +533,38 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     else want_pop = true;
                 }
             }
+            RT_SCOUNT(c_culls, (unsigned)__popcll(__ballot(boxes)));
         } else if (pick == K_TRI) {
             if (run) { // ---- one exact triangle test (kdtree.cpp:105)
                 const double2 *p = (const double2 *)(S.pool + (size_t)(cur & IDX28) * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
                 const long long w9 = __double_as_longlong(q4.y);
                 const d3 d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
+                const double best_t = ls[LS_BT * lss];
+                const unsigned long long ha = (unsigned long long)__double_as_longlong(ls[LS_HA * lss]),
+                                         hb = (unsigned long long)__double_as_longlong(ls[LS_HB * lss]);
+                const unsigned cur_list = (unsigned)ha;
                 const double2 a = sA[slot], b = sB[slot];
-                const uint4 h = sH[slot];
                 const d3 o = mk(a.x, a.y, b.x);
-                const double best_t = b.y;
                 const double t = tri_hit(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d);
-                count(LC_DONE, 1);
                 if (t > EPS) {
                     const int rk = (int)(w9 >> 32);
                     // strict < keeps the earlier of two equal distances; inside one list "earlier"
                     // is the lower rank, across lists it is the list visited first
-                    if (t < best_t || (t == best_t && h.w == h.x && rk < (int)h.z)) {
-                        sB[slot].y = t;
-                        sH[slot] = make_uint4(h.x, (unsigned)w9 & ~TRI_LAST, (unsigned)rk, h.x);
+                    if (t < best_t || (t == best_t && (unsigned)(hb >> 32) == cur_list && rk < (int)(unsigned)hb)) {
+                        ls[LS_BT * lss] = t;
+                        ((unsigned *)&ls[LS_HA * lss])[1] = (unsigned)w9 & ~TRI_LAST;
+                        ls[LS_HB * lss] = __longlong_as_double((long long)((unsigned long long)(unsigned)rk | ((unsigned long long)cur_list << 32)));
                     }
                     if (t < 1e10) st |= ST_FLAG;
                 }
                 if ((cur & IT_CHAIN) && !((unsigned)w9 & TRI_LAST)) next = cur + 5u; // the list's next triangle
                 else want_pop = true;
             }
+            RT_SCOUNT(c_done, most);
         } else {
+            bool ev_ray = false, ev_shade = false;
             if (run) { // ---- traversal finished (or nothing started yet)
-                if ((scnt[LC_TRIS][lane] | scnt[LC_VISITS][lane] | scnt[LC_CULLS][lane] | scnt[LC_DONE][lane] | scnt[LC_RAYS][lane]) >> 30) fold();
                 bool go_on = false, need_primary = false, need_work = false;
                 d3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
                 const unsigned long long wp = (unsigned long long)__double_as_longlong(ls[LS_PST * lss]);
@@ -576,14 +580,14 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 if (have_hit) {
                     const double2 a = sA[slot], b = sB[slot];
                     const d3 o = mk(a.x, a.y, b.x), d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
+                    const double to = ls[LS_BT * lss];
+                    const int tpos = (int)((const unsigned *)&ls[LS_HA * lss])[1];
                     double ts;
                     int ids;
                     trace_spheres(S, o, d, ts, ids);
-                    const double to = b.y;
-                    const int tpos = (int)sH[slot].y;
                     const bool fo = to < 1e10, fs = ts < 1e10;
                     if (TRACE) {
-                        if (fo && !(ts < to)) count(LC_SHADES, 1);
+                        if (fo && !(ts < to)) ev_shade = true;
                         tri_id[outk] = fo ? S.tshade[tpos].gid : -1;
                         tri_t[outk] = to;
                         sph_id[outk] = fs ? ids : -1;
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                             n = ld3(sh->nc);
                             f = ld3(sh->col); type = sh->type; lig = ld3(sh->lig);
                             if (primary && sub == 0 && smp == 0 && prim) prim[outk] = sh->gid;
-                            count(LC_SHADES, 1);
+                            ev_shade = true;
                         }
                         const d3 nl = dot(n, d) < 0 ? n : n * -1.0;
                         if (lig.x != 0 || lig.y != 0 || lig.z != 0) {
@@ -756,21 +760,24 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 if (go_on) { // KdTree::check on the root (raytrace.cpp:46)
                     const double ix = fabs(rd.x) < 1e-150 ? 1e300 : 1.0 / rd.x, iy = fabs(rd.y) < 1e-150 ? 1e300 : 1.0 / rd.y,
                                  iz = fabs(rd.z) < 1e-150 ? 1e300 : 1.0 / rd.z;
-                    float2 md;
-                    md.x = 0.0f;
-                    md.y = ray_margin_factor(S.cen, S.reach, S.absn, ro.x, ro.y, ro.z, sqrt(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z));
+                    const float gf = ray_margin_factor(S.cen, S.reach, S.absn, ro.x, ro.y, ro.z, sqrt(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z));
                     sA[slot] = make_double2(ro.x, ro.y);
-                    sB[slot] = make_double2(ro.z, 1e20);
-                    sC[slot] = make_double2(ix, iy);
-                    sD[slot] = make_double2(iz, __builtin_bit_cast(double, md));
-                    sH[slot] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFEu);
+                    sB[slot] = make_double2(ro.z, ix);
+                    sC[slot] = make_double2(iy, iz);
                     ls[LS_V * lss] = rd.x; ls[(LS_V + 1) * lss] = rd.y; ls[(LS_V + 2) * lss] = rd.z;
+                    ls[LS_BT * lss] = 1e20;
+                    ls[LS_HA * lss] = __longlong_as_double(-1ll);                   // no list, no triangle
+                    ls[LS_HB * lss] = __longlong_as_double((long long)0xFFFFFFFE00000000ull); // a list that is never current
+                    ls[LS_G * lss] = __longlong_as_double((long long)(unsigned long long)__float_as_uint(gf));
                     st = 0;
                     sp = 0;
-                    count(LC_RAYS, 1);
+                    ev_ray = true;
                     // next stays 0: the root node
                 } else want_pop = true; // sp is 0: the slot stays idle (done, or out of work)
             }
+            RT_SCOUNT(c_rays, (unsigned)__popcll(__ballot(ev_ray)));
+            RT_SCOUNT(c_shades, (unsigned)__popcll(__ballot(ev_shade)));
+            if (c_iters >> 24) flush();
         }
 
         // ---- common tail for the lanes that ran: push, pop, publish the slot's next item
@@ -780,7 +787,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 if (sp == 0) next = IT_END;
                 else {
                     sp--;
-                    next = sp < LDS_STACK ? stk[sp][slot] : S.ovf[(unsigned)(sp - LDS_STACK) * (unsigned)S.n_slots + gslot0 + (unsigned)slot];
+                    if (sp < LDS_STACK) next = stk[sp][slot];
+                    else next = S.ovf[(unsigned)(sp - LDS_STACK) * (unsigned)S.n_slots + gslot0 + (unsigned)slot];
                 }
             }
             const unsigned nk = done ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
@@ -790,28 +798,11 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         }
     }
 
-    // ---- work counters: per-lane totals -> wavefront sum -> one atomic per counter
-    fold();
-    unsigned long long tot[N_STATS];
-#pragma unroll
-    for (int k = 0; k < N_STATS; k++) tot[k] = 0;
-    tot[ST_RAYS] = S.tstat[(size_t)LC_RAYS * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
-    tot[ST_VISITS] = S.tstat[(size_t)LC_VISITS * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
-    tot[ST_TRIS] = S.tstat[(size_t)LC_TRIS * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
-    tot[ST_SHADES] = S.tstat[(size_t)LC_SHADES * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
-    tot[ST_DONE] = S.tstat[(size_t)LC_DONE * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
-    tot[ST_CULLS] = S.tstat[(size_t)LC_CULLS * (gridDim.x * WAVE) + blockIdx.x * WAVE + lane];
-    tot[ST_SPHS] = tot[ST_RAYS] * (unsigned)S.n_sph; // every traced ray scans all spheres (sphere.cpp:3-14)
-#pragma unroll
-    for (int k = 0; k < N_STATS; k++)
-        for (int off = 32; off > 0; off >>= 1) tot[k] += __shfl_down(tot[k], off, 64);
-    tot[ST_ITERS] = c_iters;
-    tot[ST_LANES] = c_lanes;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < N_STATS; k++)
-            if (tot[k]) atomicAdd(gstats + k, tot[k]);
-    }
+    // ---- work counters
+    flush();
+    for (int off = 32; off > 0; off >>= 1) l_tris += __shfl_down(l_tris, off, 64);
+    if (lane == 0 && l_tris) atomicAdd(gstats + ST_TRIS, l_tris);
+#undef RT_SCOUNT
 }
 
 __global__ void k_fp64(int op, long long n, const double *a, const double *b, double *out) {
@@ -846,7 +837,7 @@ struct rt_scene {
     int dev = 0;
     DevScene d{};
     void *pool = nullptr, *tshade = nullptr, *sph = nullptr, *sshade = nullptr;
-    void *ovf = nullptr, *lstate = nullptr, *tstat = nullptr;
+    void *ovf = nullptr, *lstate = nullptr;
     int tree_depth = 0;
     int grid = 0;               // persistent workgroups
     unsigned *d_counter = nullptr; // [0] block counter
@@ -1223,7 +1214,6 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     hipError_t e = hipSuccess;
     if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_slots * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&s->lstate, (size_t)LS_WORDS * n_slots * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&s->tstat, (size_t)6 * s->grid * WAVE * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_counter, 16);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
@@ -1239,7 +1229,6 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->d.sshade = (const SphShade *)s->sshade;
     s->d.ovf = (unsigned *)s->ovf;
     s->d.lstate = (double *)s->lstate;
-    s->d.tstat = (unsigned long long *)s->tstat;
     s->d.reach = std::sqrt(lg2) * 1.000001;
     s->d.absn = 0;
     for (int k = 0; k < 3; k++) {
@@ -1264,7 +1253,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->tstat, s->d_counter, s->d_stats, s->d_tiles};
+    void *ptrs[] = {s->pool, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->d_counter, s->d_stats, s->d_tiles};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
