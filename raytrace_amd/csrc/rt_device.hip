@@ -70,11 +70,11 @@ constexpr int N_STATS = 9;
 constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly, longer ones get a hierarchy
 
 // Every traversal record lives in ONE pool addressed in 16-byte granules, and a work item carries
-// the granule of its record, so a lane fetches "the record of my next item" with the same five
-// 16-byte loads whatever the item is:
-//   node i        granule 8*i      NodeRec (64 B) followed by its ListRec (64 B)
-//   cull record   4 granules       CullRec (64 B)
-//   triangle      5 granules       TriRec (80 B)
+// the granule of its record:
+//   node i        granule 4*i             NodeRec (64 B)
+//   its own list  granule g_list + 8*i    QuadRec (128 B): the list's start
+//   cull record   8 granules              QuadRec (128 B)
+//   triangle      5 granules              TriRec (80 B)
 struct __attribute__((aligned(16))) NodeRec { // one kd-tree node (KdTree, kdtree.h:96-116)
     double mi[3], ma[3];
     double split;
@@ -83,23 +83,18 @@ struct __attribute__((aligned(16))) NodeRec { // one kd-tree node (KdTree, kdtre
 };
 static_assert(sizeof(NodeRec) == 64, "NodeRec must be 64 bytes");
 
-// Boxes of two children (exact bounds rounded OUTWARD to single precision) and the children as
-// work items.  A CullRec is an inner node of a long own list's culling hierarchy; a ListRec is the
-// hierarchy's root merged with what the node's "near child finished" step needs.
-struct __attribute__((aligned(16))) CullRec {
-    float lo0[3], hi0[3], lo1[3], hi1[3];
-    unsigned a, b;
-    double pad;
+// Boxes of up to four children (exact bounds rounded OUTWARD to single precision) and the children
+// as work items (0 = no child).  As a cull record it is an inner node of a long own list's culling
+// hierarchy; as a node's list record it is the hierarchy's root merged with what the node's "near
+// child finished" step needs.
+struct __attribute__((aligned(16))) QuadRec {
+    float lo[4][3], hi[4][3]; // long lists only
+    unsigned item[4];         // long list: the child items; short list: item[0] = chained item of the first triangle
+    unsigned right;           // list record: granule of the node's right child (0 = none), for the far-child step
+    unsigned meta;            // list record: bits of the (float) margin coefficient K, or LIST_SHORT | length
+    unsigned pad[2];
 };
-static_assert(sizeof(CullRec) == 64, "CullRec must be 64 bytes");
-
-struct __attribute__((aligned(16))) ListRec { // a node's own list (KdTree::node)
-    float lo0[3], hi0[3], lo1[3], hi1[3]; // long lists only
-    unsigned a, b;  // long list: the two child items; short list: a = chained item of the first triangle
-    unsigned right; // granule of the node's right child (0 = none), for the far-child step
-    unsigned meta;  // long list: bits of the (float) margin coefficient K; short: LIST_SHORT | length
-};
-static_assert(sizeof(ListRec) == 64, "ListRec must be 64 bytes");
+static_assert(sizeof(QuadRec) == 128, "QuadRec must be 128 bytes");
 constexpr unsigned LIST_SHORT = 0x80000000u;
 
 struct __attribute__((aligned(16))) TriRec {
@@ -130,6 +125,7 @@ struct DevScene {
     double cen[3]; // centre of the scene's vertex box
     double reach;  // its summed half extents + the scene's longest triangle edge
     double absn;   // |centre|_1 + summed half extents
+    unsigned g_list; // granule of node 0's list record
     double padc;   // constant part of the node-box padding: 2.5e-5 + 4e-12 * (largest sum of |box coordinates| of a node)
     int n_sph;
     int ovf_depth;
@@ -478,7 +474,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     // kdtree.cpp:119-127 (left of the plane), 128-136 (right of it), 137-141 (on it: only
                     // the child the ray points into)
                     const bool nearL = hasL & (lt | (!gt & vneg)), nearR = hasR & !nearL & (gt | (!lt & vpos));
-                    const unsigned near = nearL ? node + 8 : nearR ? right : 0u;
+                    const unsigned near = nearL ? node + 4 : nearR ? right : 0u;
                     const unsigned farkind = (lt & hasR & vpos) ? 2u : (gt & hasL & vneg) ? 1u : 0u; // 1: left child, 2: right child
                     // the own list and the far child come after the near subtree; the frame's flag
                     // travels in the item and the near subtree starts with a clean one
@@ -491,46 +487,70 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             RT_SCOUNT(c_visits, most);
         } else if (pick == K_CULL) {
             bool boxes = false;
-            if (run) { // ---- two child boxes of a list's hierarchy; for an after item, the list's start
-                const unsigned g = (cur & IT_AFTER) ? (cur & IDX28) + 4u : (cur & IDX29);
-                const double2 *p = (const double2 *)(S.pool + (size_t)g * 16);
-                const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
+                const unsigned g = (cur & IT_AFTER) ? S.g_list + 2u * (cur & IDX28) : (cur & IDX28);
+                const float4 *p = (const float4 *)(S.pool + (size_t)g * 16);
+                const float4 f0 = p[0], f1 = p[1], f2 = p[2], f3 = p[3], f4 = p[4], f5 = p[5];
+                const uint4 it = *(const uint4 *)(p + 6), w7 = *(const uint4 *)(p + 7);
                 const unsigned gw = ((const unsigned *)&ls[LS_G * lss])[0]; // the ray's margin factor, for a list's first step
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
                 const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
                 float mg = first ? mg0 : mg1;
-                const float2 f0 = __builtin_bit_cast(float2, q0.x), f1 = __builtin_bit_cast(float2, q0.y),
-                             f2 = __builtin_bit_cast(float2, q1.x), f3 = __builtin_bit_cast(float2, q1.y),
-                             f4 = __builtin_bit_cast(float2, q2.x), f5 = __builtin_bit_cast(float2, q2.y);
-                const double lo0[3] = {f0.x, f0.y, f1.x}, hi0[3] = {f1.y, f2.x, f2.y};
-                const double lo1[3] = {f3.x, f3.y, f4.x}, hi1[3] = {f4.y, f5.x, f5.y};
-                const long long w6 = __double_as_longlong(q3.x);
-                const unsigned ia = (unsigned)w6, ib = (unsigned)(w6 >> 32);
                 boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
-                    const long long w7 = __double_as_longlong(q3.y);
-                    const unsigned right = (unsigned)w7, meta = (unsigned)(w7 >> 32);
+                    const unsigned right = w7.x, meta = w7.y;
                     const unsigned node = cur & IDX28, farkind = (cur >> 28) & 3;
                     const bool near_hit = (st & ST_FLAG) != 0;         // what the near child's check() returned
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
-                    if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 8 : right); // kdtree.cpp:124,133: after the list
+                    if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list
                     ((unsigned *)&ls[LS_HA * lss])[0] = node;            // the list now being scanned
                     if (meta & LIST_SHORT) { // up to SMALL_LIST triangles: a chain of tri steps in list order
                         boxes = false;
                         if ((meta & 0xFF) == 0) want_pop = true;
-                        else next = ia;
+                        else next = it.x;
                     } else { // inflation of this list's boxes, see ray_margin_factor(); a larger one only culls less
                         mg = __uint_as_float(meta) * __uint_as_float(gw);
                         if (first) mg0 = mg; else mg1 = mg;
                     }
                 }
                 if (boxes) {
+                    // slab test of the four inflated boxes: t = (plane -/+ m - s) * inv as one fused
+                    // multiply-add per plane; the fusion's rounding is covered by the inflation
                     const double m2 = (double)mg;
-                    const bool h0 = slab_hit(lo0, hi0, m2, s, inv), h1 = slab_hit(lo1, hi1, m2, s, inv);
-                    if (h0 && h1) { push_item = ib; next = ia; }
-                    else if (h0) next = ia;
-                    else if (h1) next = ib;
-                    else want_pop = true;
+                    double A[3], B[3];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { A[i] = -((s[i] + m2) * inv[i]); B[i] = -((s[i] - m2) * inv[i]); }
+                    const float lo[4][3] = {{f0.x, f0.y, f0.z}, {f0.w, f1.x, f1.y}, {f1.z, f1.w, f2.x}, {f2.y, f2.z, f2.w}};
+                    const float hi[4][3] = {{f3.x, f3.y, f3.z}, {f3.w, f4.x, f4.y}, {f4.z, f4.w, f5.x}, {f5.y, f5.z, f5.w}};
+                    const unsigned item[4] = {it.x, it.y, it.z, it.w};
+                    bool hit[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        double tmin = 0.0, tmax = 1e300;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            const double t1 = __builtin_fma((double)lo[k][i], inv[i], A[i]), t2 = __builtin_fma((double)hi[k][i], inv[i], B[i]);
+                            tmin = fmax(tmin, fmin(t1, t2));
+                            tmax = fmin(tmax, fmax(t1, t2));
+                        }
+                        hit[k] = (tmin <= tmax) & (item[k] != 0);
+                    }
+                    // the first child that is met continues, the others go on the stack
+                    const int n1 = hit[0], n2 = n1 + hit[1], n3 = n2 + hit[2], n4 = n3 + hit[3];
+                    if (n4 == 0) want_pop = true;
+                    else {
+                        next = hit[0] ? item[0] : hit[1] ? item[1] : hit[2] ? item[2] : item[3];
+                        if (sp + 3 <= LDS_STACK) { // the usual case: room for all three in LDS
+                            if (hit[1] & (n1 > 0)) stk[sp + n1 - 1][slot] = item[1];
+                            if (hit[2] & (n2 > 0)) stk[sp + n2 - 1][slot] = item[2];
+                            if (hit[3] & (n3 > 0)) stk[sp + n3 - 1][slot] = item[3];
+                            sp += n4 - 1;
+                        } else {
+                            if (hit[1] & (n1 > 0)) push(item[1]);
+                            if (hit[2] & (n2 > 0)) push(item[2]);
+                            if (hit[3] & (n3 > 0)) push(item[3]);
+                        }
+                    }
                 }
             }
             RT_SCOUNT(c_culls, (unsigned)__popcll(__ballot(boxes)));
@@ -853,10 +873,10 @@ struct rt_scene {
 namespace {
 
 // Culling hierarchy for one long own list: median splits of the triangle centroids along the
-// widest axis down to single triangles.  Every inner record holds the boxes of its two children
-// (exact bounds rounded OUTWARD to single precision) and the children as work items, so one
-// 64-byte fetch decides both subtrees and a triangle is only fetched when its own box is met.
-// The root of a list's hierarchy is stored in the node's ListRec.
+// widest axis, two levels per record, down to single triangles.  Every record holds the boxes of
+// its (up to four) children (exact bounds rounded OUTWARD to single precision) and the children as
+// work items, so one 128-byte fetch decides four subtrees and a triangle is only fetched when its
+// own box is met.  The root of a list's hierarchy is stored in the node's list record.
 // `order[first..first+count)` is permuted into the hierarchy's left-to-right leaf order.
 struct CullTri { double lo[3], hi[3], c[3]; int src; };
 
@@ -864,59 +884,81 @@ float f_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextaft
 float f_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; }
 
 struct CullBuild {
-    std::vector<CullRec> *out;
+    std::vector<QuadRec> *out;
     std::vector<CullTri> *bt;
     unsigned cull_base, tri_base; // granules
     int first;                    // list position of the range's first triangle
     int max_depth;
 };
 
-unsigned cull_item(CullBuild &B, int a, int b, int depth, double lo[3], double hi[3]);
+// number of records the hierarchy of a range of n >= 2 triangles takes (the splits depend on n only)
+size_t quad_count(int n) {
+    size_t k = 1;
+    const int h[2] = {n / 2, n - n / 2};
+    for (int i = 0; i < 2; i++) {
+        if (h[i] < 2) continue;
+        const int q[2] = {h[i] / 2, h[i] - h[i] / 2};
+        for (int j = 0; j < 2; j++)
+            if (q[j] >= 2) k += quad_count(q[j]);
+    }
+    return k;
+}
 
-// splits [a, b) (b - a >= 2), builds both halves, fills the two-box record `r`, returns the union box
-void cull_split(CullBuild &B, int a, int b, int depth, float (&lo0)[3], float (&hi0)[3], float (&lo1)[3], float (&hi1)[3],
-                unsigned &ia, unsigned &ib, double lo[3], double hi[3]) {
-    std::vector<CullTri> &bt = *B.bt;
+int cull_median(std::vector<CullTri> &bt, int a, int b) { // partitions [a, b) around its median, returns the split point
     double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
     for (int i = a; i < b; i++)
         for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], bt[i].c[k]); chi[k] = std::max(chi[k], bt[i].c[k]); }
     int ax = 0;
     if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
     if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
-    const int mid = (a + b) / 2;
+    const int mid = a + (b - a) / 2;
     std::nth_element(bt.begin() + a, bt.begin() + mid, bt.begin() + b, [ax](const CullTri &x, const CullTri &y) {
         return x.c[ax] < y.c[ax] || (x.c[ax] == y.c[ax] && x.src < y.src);
     });
-    double l0[3], h0[3], l1[3], h1[3];
-    ia = cull_item(B, a, mid, depth + 1, l0, h0);
-    ib = cull_item(B, mid, b, depth + 1, l1, h1);
-    for (int k = 0; k < 3; k++) {
-        lo0[k] = f_down(l0[k]); hi0[k] = f_up(h0[k]);
-        lo1[k] = f_down(l1[k]); hi1[k] = f_up(h1[k]);
-        lo[k] = std::min(l0[k], l1[k]); hi[k] = std::max(h0[k], h1[k]);
-    }
+    return mid;
 }
 
-// the work item for the range [a, b) and its exact bounds
-unsigned cull_item(CullBuild &B, int a, int b, int depth, double lo[3], double hi[3]) {
+// fills `q` for the range [a, b) (b - a >= 2), builds the records below it, returns the union box
+void cull_fill(CullBuild &B, int a, int b, int depth, QuadRec &q, double lo[3], double hi[3]) {
     if (depth > B.max_depth) B.max_depth = depth;
-    if (b - a == 1) {
-        const CullTri &t = (*B.bt)[a];
-        for (int k = 0; k < 3; k++) { lo[k] = t.lo[k]; hi[k] = t.hi[k]; }
-        return IT_TRI | (B.tri_base + 5u * (unsigned)(B.first + a));
+    std::vector<CullTri> &bt = *B.bt;
+    int r[5], nr = 0; // child range boundaries
+    const int mid = cull_median(bt, a, b);
+    r[nr++] = a;
+    if (mid - a >= 2) r[nr++] = cull_median(bt, a, mid);
+    r[nr++] = mid;
+    if (b - mid >= 2) r[nr++] = cull_median(bt, mid, b);
+    r[nr] = b;
+    for (int k = 0; k < 3; k++) { lo[k] = 1e300; hi[k] = -1e300; }
+    for (int c = 0; c < 4; c++) {
+        q.item[c] = 0;
+        for (int k = 0; k < 3; k++) { q.lo[c][k] = 0; q.hi[c][k] = 0; }
     }
-    const size_t me = B.out->size();
-    B.out->emplace_back();
-    CullRec r;
-    cull_split(B, a, b, depth, r.lo0, r.hi0, r.lo1, r.hi1, r.a, r.b, lo, hi);
-    r.pad = 0;
-    (*B.out)[me] = r;
-    return IT_CULL | (B.cull_base + 4u * (unsigned)me);
+    for (int c = 0; c < nr; c++) {
+        const int ca = r[c], cb = r[c + 1];
+        double l[3], h[3];
+        if (cb - ca == 1) {
+            for (int k = 0; k < 3; k++) { l[k] = bt[ca].lo[k]; h[k] = bt[ca].hi[k]; }
+            q.item[c] = IT_TRI | (B.tri_base + 5u * (unsigned)(B.first + ca));
+        } else {
+            const size_t me = B.out->size();
+            B.out->emplace_back();
+            QuadRec sub;
+            memset(&sub, 0, sizeof(sub));
+            cull_fill(B, ca, cb, depth + 1, sub, l, h);
+            (*B.out)[me] = sub;
+            q.item[c] = IT_CULL | (B.cull_base + 8u * (unsigned)me);
+        }
+        for (int k = 0; k < 3; k++) {
+            q.lo[c][k] = f_down(l[k]); q.hi[c][k] = f_up(h[k]);
+            lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]);
+        }
+    }
 }
 
-// fills the ListRec of a list longer than SMALL_LIST and permutes order[first..first+count)
-void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<CullRec> &cull, unsigned cull_base,
-                unsigned tri_base, ListRec &li, int &max_depth) {
+// fills the list record of a list longer than SMALL_LIST and permutes order[first..first+count)
+void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<QuadRec> &cull, unsigned cull_base,
+                unsigned tri_base, QuadRec &li, int &max_depth) {
     std::vector<CullTri> bt((size_t)count);
     double lmax2 = 0;
     for (int j = 0; j < count; j++) {
@@ -936,7 +978,7 @@ void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &
     }
     CullBuild B = {&cull, &bt, cull_base, tri_base, first, 0};
     double lo[3], hi[3];
-    cull_split(B, 0, count, 1, li.lo0, li.hi0, li.lo1, li.hi1, li.a, li.b, lo, hi);
+    cull_fill(B, 0, count, 1, li, lo, hi);
     max_depth = std::max(max_depth, B.max_depth);
     for (int j = 0; j < count; j++) order[first + j] = bt[j].src;
     float kf = f_up(2.0 * (1e-9 * lmax2 + 1e-10) * 1.000001); // the list's margin coefficient, rounded up
@@ -1105,14 +1147,15 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (dev < 0 || dev >= ndev) return fail(RT_E_INVALID, "device %d not in [0,%d)", dev, ndev);
     HIP_TRY(hipSetDevice(dev));
 
-    // pool layout in 16-byte granules: nodes (NodeRec + ListRec = 8 each), cull records (4), triangles (5)
+    // pool layout in 16-byte granules: nodes (4 each), their list records (8 each), cull records (8), triangles (5)
     size_t n_cull = 0;
     for (int i = 0; i < D->n_nodes; i++)
-        if (D->node_count[i] > SMALL_LIST) n_cull += (size_t)D->node_count[i] - 2; // inner records below the root
-    const size_t g_cull = 8 * (size_t)D->n_nodes, g_tri = g_cull + 4 * n_cull, g_end = g_tri + 5 * (size_t)D->n_tris + 2;
+        if (D->node_count[i] > SMALL_LIST) n_cull += quad_count(D->node_count[i]) - 1; // records below the root
+    const size_t g_list = (4 * (size_t)D->n_nodes + 7) / 8 * 8, g_cull = g_list + 8 * (size_t)D->n_nodes, g_tri = g_cull + 8 * n_cull,
+                 g_end = g_tri + 5 * (size_t)D->n_tris + 3;
     if (g_end > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
     std::vector<char> pool(g_end * 16, 0);
-    std::vector<CullRec> cull;
+    std::vector<QuadRec> cull;
     cull.reserve(n_cull);
     std::vector<int> order((size_t)D->n_list); // device position -> entry of list_tri
     for (int i = 0; i < D->n_list; i++) order[i] = i;
@@ -1121,22 +1164,22 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         NodeRec n;
         for (int k = 0; k < 3; k++) { n.mi[k] = D->node_box[6 * i + k]; n.ma[k] = D->node_box[6 * i + 3 + k]; }
         n.split = D->node_split[i];
-        n.right = D->node_right[i] > 0 ? 8u * (unsigned)D->node_right[i] : 0u;
+        n.right = D->node_right[i] > 0 ? 4u * (unsigned)D->node_right[i] : 0u;
         n.info = (unsigned)D->node_axis[i] | (D->node_left[i] >= 0 ? 4u : 0u) | ((unsigned)D->node_count[i] << 3);
-        ListRec li;
+        QuadRec li;
         memset(&li, 0, sizeof(li));
-        li.right = n.right;
         const int cnt = D->node_count[i], first = D->node_first[i];
         if (cnt > SMALL_LIST) build_list(D, first, cnt, order, cull, (unsigned)g_cull, (unsigned)g_tri, li, cull_depth);
         else {
             li.meta = LIST_SHORT | (unsigned)cnt;
-            li.a = IT_TRI | IT_CHAIN | ((unsigned)g_tri + 5u * (unsigned)first);
+            li.item[0] = IT_TRI | IT_CHAIN | ((unsigned)g_tri + 5u * (unsigned)first);
         }
-        memcpy(&pool[(size_t)i * 128], &n, 64);
-        memcpy(&pool[(size_t)i * 128 + 64], &li, 64);
+        li.right = n.right;
+        memcpy(&pool[(size_t)i * 64], &n, 64);
+        memcpy(&pool[(g_list + 8 * (size_t)i) * 16], &li, 128);
     }
     if (cull.size() != n_cull) return fail(RT_E_INVALID, "internal: culling hierarchy size mismatch");
-    if (n_cull) memcpy(&pool[g_cull * 16], cull.data(), n_cull * sizeof(CullRec));
+    if (n_cull) memcpy(&pool[g_cull * 16], cull.data(), n_cull * sizeof(QuadRec));
     std::vector<unsigned char> last((size_t)D->n_list, 0); // device position is the last of its own list
     for (int i = 0; i < D->n_nodes; i++)
         if (D->node_count[i] > 0) last[(size_t)D->node_first[i] + D->node_count[i] - 1] = 1;
@@ -1201,7 +1244,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->grid = pr.multiProcessorCount * per_cu;
     const int n_slots = s->grid * SLOTS;
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
-    const int need_depth = D->tree_depth + cull_depth + SMALL_LIST + 3;
+    const int need_depth = D->tree_depth + 3 * cull_depth + 4;
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK : 0;
     if ((long long)ovf_depth * n_slots >= (1ll << 31)) {
         rt_free_scene(s);
@@ -1243,6 +1286,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         if (!(b <= boxsum)) boxsum = b; // also takes a NaN, which then disables the shortcut
     }
     s->d.padc = 2.5e-5 + 4e-12 * boxsum;
+    s->d.g_list = (unsigned)g_list;
     s->d.n_sph = D->n_spheres;
     s->d.ovf_depth = ovf_depth;
     s->d.n_slots = n_slots;
