@@ -64,7 +64,7 @@ constexpr double EPS = 1e-5;  // point.h:7
 constexpr int WAVE = 64;          // threads per workgroup: one wavefront
 constexpr int RAYS_PER_LANE = 2;  // ray slots each lane chooses from
 constexpr int SLOTS = WAVE * RAYS_PER_LANE; // ray slots per workgroup
-constexpr int LDS_STACK = 14;     // traversal-stack levels kept in LDS
+constexpr int LDS_STACK = 10;     // traversal-stack levels kept in LDS
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 constexpr int N_STATS = 9;
 constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly, longer ones get a hierarchy
@@ -321,8 +321,10 @@ enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13
        LS_HB = 20, LS_G = 21, LS_PEND = 22 };
 constexpr int PEND_WORDS = 10;
 constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
-// per-slot flags word in LDS: stack pointer (bits 0-7), the frame's "has a hit" flag (8)
-constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u;
+// per-slot flags word in LDS: stack pointer (bits 0-7), the frame's "has a hit" flag (8), the kind
+// of step the slot waits for (12-14)
+constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u, ST_KEEP = 0xFFFu;
+constexpr int ST_KIND = 12;
 
 // The whole path -- camera ray, KdTree::check without recursion, check_node, sphere scan, radiance()
 // as a loop -- is cut into steps of four kinds:
@@ -331,15 +333,15 @@ constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u;
 //            also does the bookkeeping of "the node's near child has returned"   (kdtree.cpp:122-125)
 //     tri    one exact triangle test                                            (kdtree.cpp:101-107)
 //     shade  sphere scan, material, next ray / next path / next pixel           (raytrace.cpp:41-95,196-205)
-// A workgroup is ONE wavefront that owns SLOTS = 2 x 64 ray slots.  A slot is a complete path
-// tracer state: its ray, running best hit, flags and the top of its traversal stack live in LDS
-// ([field][slot], conflict free), the shading-only state lives in HBM, and NOTHING about a ray is
-// held in registers between steps.  Each iteration the wavefront votes for the kind of step that
-// most lanes can serve from one of their two slots, every such lane runs that step for its slot
-// (state from LDS, record from the pool, both loads issued together), and writes the few words
-// that changed.  Because the 64 rays of a packet diverge completely after the first bounce, this
-// keeps many lanes active per executed instruction, and the step bodies are straight-line code
-// without loop-carried registers.
+// A workgroup is ONE wavefront that owns SLOTS = 128 ray slots.  A slot is a complete path tracer
+// state: its ray origin and inverse direction, its current item, flags and the top of its
+// traversal stack live in LDS, the rest (direction, best hit, shading state) in HBM, and NOTHING
+// about a ray is held in registers between steps.  Each iteration the wavefront votes for the kind
+// of step most of its 128 slots wait for, the (up to 64) slots of that kind are handed to the
+// lanes in slot order, every such lane runs the step for its slot (state from LDS, record from the
+// pool, both loads issued together) and writes back the few words that changed.  Because the 64
+// rays of a packet diverge completely after the first bounce, this keeps most lanes active per
+// executed instruction, and the step bodies are straight-line code without loop-carried registers.
 //
 // TRACE = false: slots pull pixels (8x8 blocks, one slot per pixel) from an atomic counter and
 // run each pixel's 4*samps paths in the reference's order.  TRACE = true: slots pull explicit rays
@@ -352,20 +354,22 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     __shared__ double2 sA[SLOTS]; // origin x, y
     __shared__ double2 sB[SLOTS]; // origin z, 1/direction x
     __shared__ double2 sC[SLOTS]; // 1/direction y, z
+    __shared__ uint2 sW[SLOTS];   // current item; flags word
+    __shared__ float sM[SLOTS];   // inflation of the current list's culling boxes
     __shared__ unsigned stk[LDS_STACK][SLOTS];
+    __shared__ uint2 sQ[WAVE];    // this iteration's lane -> slot assignment: slot | flags word << 8; item
     const int lane = threadIdx.x;
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const size_t lss = (size_t)S.n_slots;
     const unsigned gslot0 = blockIdx.x * SLOTS;
 
-    // both slots start as "nothing traced yet, needs work"
+    // all slots start as "nothing traced yet, needs work"
 #pragma unroll
-    for (int r = 0; r < RAYS_PER_LANE; r++) S.lstate[LS_PST * lss + gslot0 + lane + r * WAVE] = 0.0;
-    // the only per-ray state in registers: for each of the lane's two slots the kind of step it waits
-    // for (4 bits each), its current item, its flags word and the inflation of its current list's boxes
-    unsigned kinds = K_SHADE | (K_SHADE << 4);
-    unsigned cur0 = 0, cur1 = 0, st0 = 0, st1 = 0;
-    float mg0 = 0.0f, mg1 = 0.0f;
+    for (int r = 0; r < RAYS_PER_LANE; r++) {
+        S.lstate[LS_PST * lss + gslot0 + lane + r * WAVE] = 0.0;
+        sW[lane + r * WAVE] = make_uint2(0u, (unsigned)K_SHADE << ST_KIND);
+    }
+    unsigned flip = 0; // alternates which half of the slots is handed out first
     // work counters: wavefront-uniform 32-bit sums of lane counts in scalar registers, flushed to
     // the 64-bit totals in HBM long before they can overflow; only the own-list lengths need a
     // per-lane sum
@@ -388,26 +392,38 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
 
     for (;;) {
-        // ---- vote: run the kind most lanes can serve
-        const unsigned k0 = kinds & 15u, k1 = kinds >> 4;
-        const unsigned km = (1u << k0) | (1u << k1);
-        int c0 = __popcll(__ballot((km & (1u << K_NODE)) != 0)), c1 = __popcll(__ballot((km & (1u << K_CULL)) != 0)),
-            c2 = __popcll(__ballot((km & (1u << K_TRI)) != 0)), c3 = __popcll(__ballot((km & (1u << K_SHADE)) != 0));
+        // ---- vote: run the kind most slots wait for; lane l looks at slots l and l + 64
+        const uint2 wA = sW[lane], wB = sW[lane + WAVE];
+        const unsigned kA = (wA.y >> ST_KIND) & 7u, kB = (wB.y >> ST_KIND) & 7u;
+        int c0 = __popcll(__ballot(kA == K_NODE)) + __popcll(__ballot(kB == K_NODE)),
+            c1 = __popcll(__ballot(kA == K_CULL)) + __popcll(__ballot(kB == K_CULL)),
+            c2 = __popcll(__ballot(kA == K_TRI)) + __popcll(__ballot(kB == K_TRI)),
+            c3 = __popcll(__ballot(kA == K_SHADE)) + __popcll(__ballot(kB == K_SHADE));
         asm("" : "+s"(c0), "+s"(c1), "+s"(c2), "+s"(c3)); // keep the comparison below in 32-bit scalar registers
         int pick = K_NODE, most = c0;
         if (c1 > most) { most = c1; pick = K_CULL; }
         if (c2 > most) { most = c2; pick = K_TRI; }
         if (c3 > most) { most = c3; pick = K_SHADE; }
         if (most == 0) break; // every slot is done
-        const bool first = k0 == (unsigned)pick;
-        const bool run = (km >> pick) & 1u;
-        const int slot = first ? lane : lane + WAVE;
+        // ---- hand the slots of that kind to the lanes: slot order, the half that goes first alternates
+        const bool inA = kA == (unsigned)pick, inB = kB == (unsigned)pick;
+        const unsigned long long mA = __ballot(inA), mB = __ballot(inB);
+        const unsigned nA = (unsigned)__popcll(mA), nB = (unsigned)__popcll(mB);
+        flip ^= 1u;
+        const unsigned posA = (flip ? nB : 0u) + (unsigned)__popcll(mA & lane_lt), posB = (flip ? 0u : nA) + (unsigned)__popcll(mB & lane_lt);
+        if (inA && posA < (unsigned)WAVE) sQ[posA] = make_uint2((unsigned)lane | (wA.y << 8), wA.x);
+        if (inB && posB < (unsigned)WAVE) sQ[posB] = make_uint2((unsigned)(lane + WAVE) | (wB.y << 8), wB.x);
+        const int nrun = most < WAVE ? most : WAVE;
+        const bool run = lane < nrun;
+        uint2 e = make_uint2(0u, 0u);
+        if (run) e = sQ[lane];
+        const int slot = (int)(e.x & (unsigned)(SLOTS - 1));
+        const unsigned cur = e.y;
+        unsigned st = (e.x >> 8) & ST_KEEP;
         double *const ls = S.lstate + gslot0 + slot; // this slot's column of the HBM state
         RT_SCOUNT(c_iters, 1);
-        RT_SCOUNT(c_lanes, most);
+        RT_SCOUNT(c_lanes, nrun);
 
-        const unsigned cur = first ? cur0 : cur1;
-        unsigned st = first ? st0 : st1;
         int sp = (int)(st & ST_SP);
         auto push = [&](unsigned item) __attribute__((always_inline)) {
             if (sp < LDS_STACK) stk[sp][slot] = item;
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     else next = after;
                 }
             }
-            RT_SCOUNT(c_visits, most);
+            RT_SCOUNT(c_visits, nrun);
         } else if (pick == K_CULL) {
             bool boxes = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
@@ -495,7 +511,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const unsigned gw = ((const unsigned *)&ls[LS_G * lss])[0]; // the ray's margin factor, for a list's first step
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
                 const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
-                float mg = first ? mg0 : mg1;
+                float mg = sM[slot];
                 boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
                     const unsigned right = w7.x, meta = w7.y;
@@ -510,7 +526,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                         else next = it.x;
                     } else { // inflation of this list's boxes, see ray_margin_factor(); a larger one only culls less
                         mg = __uint_as_float(meta) * __uint_as_float(gw);
-                        if (first) mg0 = mg; else mg1 = mg;
+                        sM[slot] = mg;
                     }
                 }
                 if (boxes) {
@@ -581,7 +597,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 if ((cur & IT_CHAIN) && !((unsigned)w9 & TRI_LAST)) next = cur + 5u; // the list's next triangle
                 else want_pop = true;
             }
-            RT_SCOUNT(c_done, most);
+            RT_SCOUNT(c_done, nrun);
         } else {
             bool ev_ray = false, ev_shade = false;
             if (run) { // ---- traversal finished (or nothing started yet)
@@ -812,9 +828,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 }
             }
             const unsigned nk = done ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
-            const unsigned ncur = next == IT_END ? 0u : next, nst = (st & ~ST_SP) | (unsigned)sp;
-            if (first) { cur0 = ncur; st0 = nst; kinds = (kinds & ~15u) | nk; }
-            else { cur1 = ncur; st1 = nst; kinds = (kinds & 15u) | (nk << 4); }
+            sW[slot] = make_uint2(next == IT_END ? 0u : next, (st & ST_FLAG) | (unsigned)sp | (nk << ST_KIND));
         }
     }
 
