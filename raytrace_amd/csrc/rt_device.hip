@@ -64,7 +64,7 @@ constexpr double EPS = 1e-5;  // point.h:7
 constexpr int WAVE = 64;          // threads per workgroup: one wavefront
 constexpr int RAYS_PER_LANE = 2;  // ray slots each lane chooses from
 constexpr int SLOTS = WAVE * RAYS_PER_LANE; // ray slots per workgroup
-constexpr int LDS_STACK = 10;     // traversal-stack levels kept in LDS
+constexpr int LDS_STACK = 8;      // the newest traversal-stack levels are kept in LDS (a ring), older ones in HBM
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 constexpr int N_STATS = 9;
 constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly, longer ones get a hierarchy
@@ -321,10 +321,10 @@ enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13
        LS_HB = 20, LS_G = 21, LS_PEND = 22 };
 constexpr int PEND_WORDS = 10;
 constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
-// per-slot flags word in LDS: stack pointer (bits 0-7), the frame's "has a hit" flag (8), the kind
-// of step the slot waits for (12-14)
-constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u, ST_KEEP = 0xFFFu;
-constexpr int ST_KIND = 12;
+// per-slot flags word in LDS: stack depth (bits 0-7), the frame's "has a hit" flag (8), the kind
+// of step the slot waits for (9-11), number of stack levels that live in HBM only (12-19)
+constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u;
+constexpr int ST_KIND = 9, ST_LO = 12;
 
 // The whole path -- camera ray, KdTree::check without recursion, check_node, sphere scan, radiance()
 // as a loop -- is cut into steps of four kinds:
@@ -419,15 +419,19 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         if (run) e = sQ[lane];
         const int slot = (int)(e.x & (unsigned)(SLOTS - 1));
         const unsigned cur = e.y;
-        unsigned st = (e.x >> 8) & ST_KEEP;
+        unsigned st = e.x >> 8;
         double *const ls = S.lstate + gslot0 + slot; // this slot's column of the HBM state
         RT_SCOUNT(c_iters, 1);
         RT_SCOUNT(c_lanes, nrun);
 
-        int sp = (int)(st & ST_SP);
+        // the stack: levels [slo, sp) are in the LDS ring (level i at i mod LDS_STACK), levels [0, slo) in HBM
+        int sp = (int)(st & ST_SP), slo = (int)((st >> ST_LO) & 0xFFu);
         auto push = [&](unsigned item) __attribute__((always_inline)) {
-            if (sp < LDS_STACK) stk[sp][slot] = item;
-            else S.ovf[(unsigned)(sp - LDS_STACK) * (unsigned)S.n_slots + gslot0 + (unsigned)slot] = item;
+            if (sp - slo == LDS_STACK) { // ring full: its oldest level moves to HBM
+                S.ovf[(unsigned)slo * (unsigned)S.n_slots + gslot0 + (unsigned)slot] = stk[slo & (LDS_STACK - 1)][slot];
+                slo++;
+            }
+            stk[sp & (LDS_STACK - 1)][slot] = item;
             sp++;
         };
         // what the step leaves behind for the common tail
@@ -556,10 +560,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     if (n4 == 0) want_pop = true;
                     else {
                         next = hit[0] ? item[0] : hit[1] ? item[1] : hit[2] ? item[2] : item[3];
-                        if (sp + 3 <= LDS_STACK) { // the usual case: room for all three in LDS
-                            if (hit[1] & (n1 > 0)) stk[sp + n1 - 1][slot] = item[1];
-                            if (hit[2] & (n2 > 0)) stk[sp + n2 - 1][slot] = item[2];
-                            if (hit[3] & (n3 > 0)) stk[sp + n3 - 1][slot] = item[3];
+                        if (sp - slo + 3 <= LDS_STACK) { // the usual case: room for all three in the ring
+                            if (hit[1] & (n1 > 0)) stk[(sp + n1 - 1) & (LDS_STACK - 1)][slot] = item[1];
+                            if (hit[2] & (n2 > 0)) stk[(sp + n2 - 1) & (LDS_STACK - 1)][slot] = item[2];
+                            if (hit[3] & (n3 > 0)) stk[(sp + n3 - 1) & (LDS_STACK - 1)][slot] = item[3];
                             sp += n4 - 1;
                         } else {
                             if (hit[1] & (n1 > 0)) push(item[1]);
@@ -806,7 +810,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     ls[LS_HB * lss] = __longlong_as_double((long long)0xFFFFFFFE00000000ull); // a list that is never current
                     ls[LS_G * lss] = __longlong_as_double((long long)(unsigned long long)__float_as_uint(gf));
                     st = 0;
-                    sp = 0;
+                    sp = 0; slo = 0;
                     ev_ray = true;
                     // next stays 0: the root node
                 } else want_pop = true; // sp is 0: the slot stays idle (done, or out of work)
@@ -823,12 +827,15 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 if (sp == 0) next = IT_END;
                 else {
                     sp--;
-                    if (sp < LDS_STACK) next = stk[sp][slot];
-                    else next = S.ovf[(unsigned)(sp - LDS_STACK) * (unsigned)S.n_slots + gslot0 + (unsigned)slot];
+                    if (sp >= slo) next = stk[sp & (LDS_STACK - 1)][slot];
+                    else { // the ring is empty: the level is in HBM
+                        slo = sp;
+                        next = S.ovf[(unsigned)sp * (unsigned)S.n_slots + gslot0 + (unsigned)slot];
+                    }
                 }
             }
             const unsigned nk = done ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
-            sW[slot] = make_uint2(next == IT_END ? 0u : next, (st & ST_FLAG) | (unsigned)sp | (nk << ST_KIND));
+            sW[slot] = make_uint2(next == IT_END ? 0u : next, (st & ST_FLAG) | (unsigned)sp | (nk << ST_KIND) | ((unsigned)slo << ST_LO));
         }
     }
 
@@ -1259,7 +1266,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     const int n_slots = s->grid * SLOTS;
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
     const int need_depth = D->tree_depth + 3 * cull_depth + 4;
-    const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK : 0;
+    const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK + 1 : 0; // levels that can move to HBM
     if ((long long)ovf_depth * n_slots >= (1ll << 31)) {
         rt_free_scene(s);
         return fail(RT_E_LIMIT, "overflow stack of %d levels x %d slots exceeds the 31-bit index", ovf_depth, n_slots);
