@@ -9,28 +9,23 @@
 //   Polygon::intersect       polygon.h:37-60
 //   Sphere::intersect / sphere_intersect   sphere.h:13-21, sphere.cpp:3-14
 //
-// Numerics: all arithmetic is FP64 in the reference's operation order; this file must be
-// compiled with -ffp-contract=off so no multiply-add is fused (the CPU path has no FMA), and
-// double divide / sqrt are the correctly rounded expansions.  Primary-hit ids and distances
-// are therefore bit-identical to the CPU path; colours differ only through sin/cos (last-ulp)
-// and through summing emission along the path front-to-back instead of back-to-front.
+// Numerics: all arithmetic that decides a result is FP64 in the reference's operation order; this
+// file must be compiled with -ffp-contract=off so no multiply-add is fused (the CPU path has no
+// FMA), and double divide / sqrt are the correctly rounded expansions.  Primary-hit ids and
+// distances are therefore bit-identical to the CPU path; colours differ only through sin/cos
+// (last-ulp) and through summing emission along the path front-to-back instead of back-to-front.
+// The conservative box tests that only decide what is SKIPPED may fuse and use single-precision
+// boxes rounded outward.
 //
-// Layout in HBM (built by rt_upload_scene):
-//   NodeRec   64 B, 64-B aligned: box (48), split (8), right child (4), info (4: axis, has-left,
-//             own-list length).  Nodes are in pre-order so the left child is node+1.
-//   ListRec   64 B per node: start and length of the node's own list, and for long lists the root
-//             of a culling hierarchy plus the data for its safety margin
-//   TriRec    80 B, 16-B aligned, grouped by own list (each triangle is in exactly one list), so a
-//             node's list is a contiguous run: p0, E1 = p1-p0, E2 = p2-p0, global id, list rank
-//   CullRec   64 B: single-precision outward-rounded boxes of two children + the two child items
-//   TriShade  80 B per triangle, same order: nc, col, lig, type (touched only on the chosen hit)
-//   SphGeom   32 B: centre, radius;  SphShade 64 B: lig, col, type
+// Layout in HBM (built by rt_upload_scene): one pool of traversal records addressed in 16-byte
+// granules (NodeRec, QuadRec, TriRec below), TriShade 80 B per triangle (nc, col, lig, type, global
+// id; touched only on the chosen hit), SphGeom 32 B (centre, radius), SphShade 64 B (lig, col,
+// type), and per ray slot a column of 8-byte words (direction, best hit, shading state).
 //
-// Execution: persistent workgroups of 4 wavefronts; each wavefront repeatedly takes one 8x8
-// pixel block (a 64-lane packet, one pixel per lane) from an atomic counter, and each lane runs
-// its pixel's 4*samps paths to completion, so the per-pixel sums happen in the reference's
-// order with no atomics.  The traversal stack lives in LDS ([level][thread], conflict-free);
-// levels beyond LDS_STACK spill to a per-thread HBM array sized from the tree depth.
+// Execution: a persistent grid of one-wavefront workgroups.  Each wavefront owns 128 ray slots
+// (one pixel's current path each); slots take pixels from an atomic counter in 8x8-block order
+// and run the pixel's 4*samps paths to completion, so the per-pixel sums happen in the
+// reference's order with no atomics.  See k_main for the scheduling.
 //
 // Long own lists.  The reference tests EVERY triangle of a visited node's own list, and its
 // median-split tree leaves thousands of straddling triangles on the top nodes.  Testing them all
