@@ -309,11 +309,10 @@ enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, S
 //   LS_OUT  low: index in the packed output (render) / ray index (trace); high: pixel x << 16 | y
 //   LS_PEND parked glass branches, PEND_WORDS each: origin, direction, throughput, depth | into << 32
 //   LS_V    ray direction;  LS_BT best distance so far
-//   LS_HA   low: current list (node granule); high: best triangle (TriShade index)
+//   LS_HA   low: best triangle (TriShade index)
 //   LS_HB   best triangle's list rank (low) and list (high)
-//   LS_G    low: the ray's margin factor (float)
 enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13, LS_OUT = 14, LS_V = 15, LS_BT = 18, LS_HA = 19,
-       LS_HB = 20, LS_G = 21, LS_PEND = 22 };
+       LS_HB = 20, LS_PEND = 21 };
 constexpr int PEND_WORDS = 10;
 constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
 // per-slot flags word in LDS: stack depth (bits 0-7), the frame's "has a hit" flag (8), the kind
@@ -351,6 +350,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     __shared__ double2 sC[SLOTS]; // 1/direction y, z
     __shared__ uint2 sW[SLOTS];   // current item; flags word
     __shared__ float sM[SLOTS];   // inflation of the current list's culling boxes
+    __shared__ float sG[SLOTS];   // the ray's margin factor
+    __shared__ unsigned sL[SLOTS]; // current list (node granule)
     __shared__ unsigned stk[LDS_STACK][SLOTS];
     __shared__ uint2 sQ[WAVE];    // this iteration's lane -> slot assignment: slot | flags word << 8; item
     const int lane = threadIdx.x;
@@ -506,8 +507,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const unsigned g = (cur & IT_AFTER) ? S.g_list + 2u * (cur & IDX28) : (cur & IDX28);
                 const float4 *p = (const float4 *)(S.pool + (size_t)g * 16);
                 const float4 f0 = p[0], f1 = p[1], f2 = p[2], f3 = p[3], f4 = p[4], f5 = p[5];
-                const uint4 it = *(const uint4 *)(p + 6), w7 = *(const uint4 *)(p + 7);
-                const unsigned gw = ((const unsigned *)&ls[LS_G * lss])[0]; // the ray's margin factor, for a list's first step
+                const uint4 it = *(const uint4 *)(p + 6);
+                uint2 w7 = make_uint2(0u, 0u);
+                if (cur & IT_AFTER) w7 = *(const uint2 *)(p + 7); // right child and list header: only a list's first step needs them
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
                 const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
                 float mg = sM[slot];
@@ -518,13 +520,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const bool near_hit = (st & ST_FLAG) != 0;         // what the near child's check() returned
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
                     if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list
-                    ((unsigned *)&ls[LS_HA * lss])[0] = node;            // the list now being scanned
+                    sL[slot] = node;                                     // the list now being scanned
                     if (meta & LIST_SHORT) { // up to SMALL_LIST triangles: a chain of tri steps in list order
                         boxes = false;
                         if ((meta & 0xFF) == 0) want_pop = true;
                         else next = it.x;
                     } else { // inflation of this list's boxes, see ray_margin_factor(); a larger one only culls less
-                        mg = __uint_as_float(meta) * __uint_as_float(gw);
+                        mg = __uint_as_float(meta) * sG[slot];
                         sM[slot] = mg;
                     }
                 }
@@ -576,9 +578,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const long long w9 = __double_as_longlong(q4.y);
                 const d3 d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
                 const double best_t = ls[LS_BT * lss];
-                const unsigned long long ha = (unsigned long long)__double_as_longlong(ls[LS_HA * lss]),
-                                         hb = (unsigned long long)__double_as_longlong(ls[LS_HB * lss]);
-                const unsigned cur_list = (unsigned)ha;
+                const unsigned cur_list = sL[slot];
                 const double2 a = sA[slot], b = sB[slot];
                 const d3 o = mk(a.x, a.y, b.x);
                 const double t = tri_hit(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d);
@@ -586,9 +586,14 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const int rk = (int)(w9 >> 32);
                     // strict < keeps the earlier of two equal distances; inside one list "earlier"
                     // is the lower rank, across lists it is the list visited first
-                    if (t < best_t || (t == best_t && (unsigned)(hb >> 32) == cur_list && rk < (int)(unsigned)hb)) {
+                    bool better = t < best_t;
+                    if (t == best_t) { // rare: the best triangle's list and rank decide
+                        const unsigned long long hb = (unsigned long long)__double_as_longlong(ls[LS_HB * lss]);
+                        better = (unsigned)(hb >> 32) == cur_list && rk < (int)(unsigned)hb;
+                    }
+                    if (better) {
                         ls[LS_BT * lss] = t;
-                        ((unsigned *)&ls[LS_HA * lss])[1] = (unsigned)w9 & ~TRI_LAST;
+                        ls[LS_HA * lss] = __longlong_as_double((long long)(unsigned long long)((unsigned)w9 & ~TRI_LAST));
                         ls[LS_HB * lss] = __longlong_as_double((long long)((unsigned long long)(unsigned)rk | ((unsigned long long)cur_list << 32)));
                     }
                     if (t < 1e10) st |= ST_FLAG;
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const double2 a = sA[slot], b = sB[slot];
                     const d3 o = mk(a.x, a.y, b.x), d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
                     const double to = ls[LS_BT * lss];
-                    const int tpos = (int)((const unsigned *)&ls[LS_HA * lss])[1];
+                    const int tpos = (int)((const unsigned *)&ls[LS_HA * lss])[0];
                     double ts;
                     int ids;
                     trace_spheres(S, o, d, ts, ids);
@@ -801,9 +806,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     sC[slot] = make_double2(iy, iz);
                     ls[LS_V * lss] = rd.x; ls[(LS_V + 1) * lss] = rd.y; ls[(LS_V + 2) * lss] = rd.z;
                     ls[LS_BT * lss] = 1e20;
-                    ls[LS_HA * lss] = __longlong_as_double(-1ll);                   // no list, no triangle
+                    ls[LS_HA * lss] = __longlong_as_double(-1ll);                   // no triangle
                     ls[LS_HB * lss] = __longlong_as_double((long long)0xFFFFFFFE00000000ull); // a list that is never current
-                    ls[LS_G * lss] = __longlong_as_double((long long)(unsigned long long)__float_as_uint(gf));
+                    sL[slot] = 0xFFFFFFFFu;
+                    sG[slot] = gf;
                     st = 0;
                     sp = 0; slo = 0;
                     ev_ray = true;
