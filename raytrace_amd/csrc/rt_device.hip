@@ -52,14 +52,20 @@
 namespace {
 
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 3 // wavefronts per SIMD the register allocation is bounded for
+#define RT_MIN_WAVES 2 // wavefronts per SIMD the register allocation is bounded for (LDS decides the real number)
 #endif
 
 constexpr double EPS = 1e-5;  // point.h:7
 constexpr int WAVE = 64;          // threads per workgroup: one wavefront
-constexpr int RAYS_PER_LANE = 2;  // ray slots each lane chooses from
+#ifndef RT_RAYS_PER_LANE
+#define RT_RAYS_PER_LANE 2
+#endif
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 16
+#endif
+constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE; // ray slots per lane of the owning wavefront
 constexpr int SLOTS = WAVE * RAYS_PER_LANE; // ray slots per workgroup
-constexpr int LDS_STACK = 8;      // the newest traversal-stack levels are kept in LDS (a ring), older ones in HBM
+constexpr int LDS_STACK = RT_LDS_STACK; // the newest traversal-stack levels are kept in LDS (a ring, a power of two), older ones in HBM
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 constexpr int N_STATS = 9;
 constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly, longer ones get a hierarchy
@@ -354,6 +360,11 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     __shared__ unsigned sL[SLOTS]; // current list (node granule)
     __shared__ unsigned stk[LDS_STACK][SLOTS];
     __shared__ uint2 sQ[WAVE];    // this iteration's lane -> slot assignment: slot | flags word << 8; item
+    static_assert(SLOTS <= 256, "a slot index is kept in 8 bits");
+#ifdef RT_LDS_PAD
+    __shared__ unsigned pad_lds[RT_LDS_PAD / 4]; // experiment: lowers the number of resident wavefronts
+    if (n_work == 0xFFFFFFFFu) { pad_lds[threadIdx.x] = n_tiles; gstats[threadIdx.x] = pad_lds[(threadIdx.x * 7) % (RT_LDS_PAD / 4)]; }
+#endif
     const int lane = threadIdx.x;
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const size_t lss = (size_t)S.n_slots;
@@ -388,32 +399,47 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
 
     for (;;) {
-        // ---- vote: run the kind most slots wait for; lane l looks at slots l and l + 64
-        const uint2 wA = sW[lane], wB = sW[lane + WAVE];
-        const unsigned kA = (wA.y >> ST_KIND) & 7u, kB = (wB.y >> ST_KIND) & 7u;
-        int c0 = __popcll(__ballot(kA == K_NODE)) + __popcll(__ballot(kB == K_NODE)),
-            c1 = __popcll(__ballot(kA == K_CULL)) + __popcll(__ballot(kB == K_CULL)),
-            c2 = __popcll(__ballot(kA == K_TRI)) + __popcll(__ballot(kB == K_TRI)),
-            c3 = __popcll(__ballot(kA == K_SHADE)) + __popcll(__ballot(kB == K_SHADE));
+        // ---- vote: run the kind most slots wait for; lane l looks at slots l, l + 64, ...
+        uint2 w[RAYS_PER_LANE];
+        unsigned kd[RAYS_PER_LANE];
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+        for (int r = 0; r < RAYS_PER_LANE; r++) {
+            w[r] = sW[lane + r * WAVE];
+            kd[r] = (w[r].y >> ST_KIND) & 7u;
+            c0 += __popcll(__ballot(kd[r] == K_NODE)); c1 += __popcll(__ballot(kd[r] == K_CULL));
+            c2 += __popcll(__ballot(kd[r] == K_TRI)); c3 += __popcll(__ballot(kd[r] == K_SHADE));
+        }
         asm("" : "+s"(c0), "+s"(c1), "+s"(c2), "+s"(c3)); // keep the comparison below in 32-bit scalar registers
         int pick = K_NODE, most = c0;
         if (c1 > most) { most = c1; pick = K_CULL; }
         if (c2 > most) { most = c2; pick = K_TRI; }
         if (c3 > most) { most = c3; pick = K_SHADE; }
         if (most == 0) break; // every slot is done
-        // ---- hand the slots of that kind to the lanes: slot order, the half that goes first alternates
-        const bool inA = kA == (unsigned)pick, inB = kB == (unsigned)pick;
-        const unsigned long long mA = __ballot(inA), mB = __ballot(inB);
-        const unsigned nA = (unsigned)__popcll(mA), nB = (unsigned)__popcll(mB);
+        // ---- hand the slots of that kind to the lanes in slot order; the direction alternates so
+        // that no group of slots is always served last
         flip ^= 1u;
-        const unsigned posA = (flip ? nB : 0u) + (unsigned)__popcll(mA & lane_lt), posB = (flip ? 0u : nA) + (unsigned)__popcll(mB & lane_lt);
-        if (inA && posA < (unsigned)WAVE) sQ[posA] = make_uint2((unsigned)lane | (wA.y << 8), wA.x);
-        if (inB && posB < (unsigned)WAVE) sQ[posB] = make_uint2((unsigned)(lane + WAVE) | (wB.y << 8), wB.x);
+        unsigned nin[RAYS_PER_LANE], tot = 0;
+        unsigned long long min_[RAYS_PER_LANE];
+#pragma unroll
+        for (int r = 0; r < RAYS_PER_LANE; r++) {
+            min_[r] = __ballot(kd[r] == (unsigned)pick);
+            nin[r] = (unsigned)__popcll(min_[r]);
+            tot += nin[r];
+        }
+        unsigned before = 0; // slots of the kind in the groups below r
+#pragma unroll
+        for (int r = 0; r < RAYS_PER_LANE; r++) {
+            const unsigned base = flip ? tot - before - nin[r] : before;
+            const unsigned pos = base + (unsigned)__popcll(min_[r] & lane_lt);
+            if (kd[r] == (unsigned)pick && pos < (unsigned)WAVE) sQ[pos] = make_uint2((unsigned)(lane + r * WAVE) | (w[r].y << 8), w[r].x);
+            before += nin[r];
+        }
         const int nrun = most < WAVE ? most : WAVE;
         const bool run = lane < nrun;
         uint2 e = make_uint2(0u, 0u);
         if (run) e = sQ[lane];
-        const int slot = (int)(e.x & (unsigned)(SLOTS - 1));
+        const int slot = (int)(e.x & 0xFFu);
         const unsigned cur = e.y;
         unsigned st = e.x >> 8;
         double *const ls = S.lstate + gslot0 + slot; // this slot's column of the HBM state
