@@ -84,8 +84,8 @@ def cpu_baseline(scene, cam_od, sizex, sizey, pkw, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=3)  # the engine clock needs about half a second of load to settle
     ap.add_argument("--workload", default="sponza")
     ap.add_argument("--sizex", type=int, default=0)
     ap.add_argument("--sizey", type=int, default=0)

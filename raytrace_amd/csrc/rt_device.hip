@@ -361,10 +361,6 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     __shared__ unsigned stk[LDS_STACK][SLOTS];
     __shared__ uint2 sQ[WAVE];    // this iteration's lane -> slot assignment: slot | flags word << 8; item
     static_assert(SLOTS <= 256, "a slot index is kept in 8 bits");
-#ifdef RT_LDS_PAD
-    __shared__ unsigned pad_lds[RT_LDS_PAD / 4]; // experiment: lowers the number of resident wavefronts
-    if (n_work == 0xFFFFFFFFu) { pad_lds[threadIdx.x] = n_tiles; gstats[threadIdx.x] = pad_lds[(threadIdx.x * 7) % (RT_LDS_PAD / 4)]; }
-#endif
     const int lane = threadIdx.x;
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const size_t lss = (size_t)S.n_slots;
