@@ -43,6 +43,8 @@ def build_workload(name, sizex, sizey):
         return scenes.bunny_class(69451, sizex or 1080, sizey or 1920), dict(rr_depth=2, rr_mode=0)
     if name == "spheres":
         return scenes.random_spheres(10000, sizex or 1080, sizey or 1920), dict(rr_depth=8, rr_mode=0)
+    if name == "lucy":
+        return scenes.lucy_class(28055742, sizex or 2160, sizey or 3840), dict(rr_depth=2, rr_mode=0)
     if name == "cornell":
         return scenes.cornell_demo(sizex or 600, sizey or 800), dict(rr_depth=5, rr_mode=1)
     if name == "sponza_small":
