@@ -73,8 +73,8 @@ constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly
 // Every traversal record lives in ONE pool addressed in 16-byte granules, and a work item carries
 // the granule of its record:
 //   node i        granule 4*i             NodeRec (64 B)
-//   its own list  granule g_list + 8*i    QuadRec (128 B): the list's start
-//   cull record   8 granules              QuadRec (128 B)
+//   its own list  granule g_list + 4*i    QuadRec (64 B): the list's start (+ an 8-byte ListHdr in its own array)
+//   cull record   4 granules              QuadRec (64 B)
 //   triangle      5 granules              TriRec (80 B)
 struct __attribute__((aligned(16))) NodeRec { // one kd-tree node (KdTree, kdtree.h:96-116)
     double mi[3], ma[3];
@@ -84,18 +84,22 @@ struct __attribute__((aligned(16))) NodeRec { // one kd-tree node (KdTree, kdtre
 };
 static_assert(sizeof(NodeRec) == 64, "NodeRec must be 64 bytes");
 
-// Boxes of up to four children (exact bounds rounded OUTWARD to single precision) and the children
-// as work items (0 = no child).  As a cull record it is an inner node of a long own list's culling
-// hierarchy; as a node's list record it is the hierarchy's root merged with what the node's "near
-// child finished" step needs.
+// Boxes of up to four children and the children as work items (0 = no child).  A box plane is
+// stored as one byte: plane = base[axis] + byte * step[axis], evaluated in single precision with
+// one fused multiply-add; the builder picks the bytes so that this very expression is <= the
+// exact lower bound and >= the exact upper bound.  As a cull record it is an inner node of a long
+// own list's culling hierarchy; as a node's list record it is the hierarchy's root (long list) or
+// carries the chained item of the list's first triangle in item[0] (short list).
 struct __attribute__((aligned(16))) QuadRec {
-    float lo[4][3], hi[4][3]; // long lists only
-    unsigned item[4];         // long list: the child items; short list: item[0] = chained item of the first triangle
-    unsigned right;           // list record: granule of the node's right child (0 = none), for the far-child step
-    unsigned meta;            // list record: bits of the (float) margin coefficient K, or LIST_SHORT | length
-    unsigned pad[2];
+    float base[3], step[3];
+    unsigned char q[4][3][2]; // [child][axis][lower, upper]
+    unsigned item[4];
 };
-static_assert(sizeof(QuadRec) == 128, "QuadRec must be 128 bytes");
+static_assert(sizeof(QuadRec) == 64, "QuadRec must be 64 bytes");
+struct ListHdr { // per node, beside its list record: what the "near child finished" step needs
+    unsigned right; // granule of the node's right child (0 = none), for the far-child step
+    unsigned meta;  // bits of the (float) margin coefficient K of a long list, or LIST_SHORT | length
+};
 constexpr unsigned LIST_SHORT = 0x80000000u;
 
 struct __attribute__((aligned(16))) TriRec {
@@ -127,6 +131,8 @@ struct DevScene {
     double reach;  // its summed half extents + the scene's longest triangle edge
     double absn;   // |centre|_1 + summed half extents
     unsigned g_list; // granule of node 0's list record
+    const ListHdr *lhdr; // per node
+    float fslack;    // part of the single-precision slab test's safety margin that depends on the scene only
     double padc;   // constant part of the node-box padding: 2.5e-5 + 4e-12 * (largest sum of |box coordinates| of a node)
     int n_sph;
     int ovf_depth;
@@ -526,18 +532,16 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         } else if (pick == K_CULL) {
             bool boxes = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
-                const unsigned g = (cur & IT_AFTER) ? S.g_list + 2u * (cur & IDX28) : (cur & IDX28);
-                const float4 *p = (const float4 *)(S.pool + (size_t)g * 16);
-                const float4 f0 = p[0], f1 = p[1], f2 = p[2], f3 = p[3], f4 = p[4], f5 = p[5];
-                const uint4 it = *(const uint4 *)(p + 6);
-                uint2 w7 = make_uint2(0u, 0u);
-                if (cur & IT_AFTER) w7 = *(const uint2 *)(p + 7); // right child and list header: only a list's first step needs them
+                const unsigned g = (cur & IT_AFTER) ? S.g_list + (cur & IDX28) : (cur & IDX28);
+                const uint4 *p = (const uint4 *)(S.pool + (size_t)g * 16);
+                const uint4 r0 = p[0], r1 = p[1], r2 = p[2], it = p[3];
+                uint2 hdr = make_uint2(0u, 0u);
+                if (cur & IT_AFTER) hdr = *(const uint2 *)(S.lhdr + ((cur & IDX28) >> 2)); // right child, list header
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
-                const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
                 float mg = sM[slot];
                 boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
-                    const unsigned right = w7.x, meta = w7.y;
+                    const unsigned right = hdr.x, meta = hdr.y;
                     const unsigned node = cur & IDX28, farkind = (cur >> 28) & 3;
                     const bool near_hit = (st & ST_FLAG) != 0;         // what the near child's check() returned
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
@@ -553,26 +557,46 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     }
                 }
                 if (boxes) {
-                    // slab test of the four inflated boxes: t = (plane -/+ m - s) * inv as one fused
-                    // multiply-add per plane; the fusion's rounding is covered by the inflation
-                    const double m2 = (double)mg;
-                    double A[3], B[3];
-#pragma unroll
-                    for (int i = 0; i < 3; i++) { A[i] = -((s[i] + m2) * inv[i]); B[i] = -((s[i] - m2) * inv[i]); }
-                    const float lo[4][3] = {{f0.x, f0.y, f0.z}, {f0.w, f1.x, f1.y}, {f1.z, f1.w, f2.x}, {f2.y, f2.z, f2.w}};
-                    const float hi[4][3] = {{f3.x, f3.y, f3.z}, {f3.w, f4.x, f4.y}, {f4.z, f4.w, f5.x}, {f5.y, f5.z, f5.w}};
+                    // Slab test of the four inflated boxes in single precision, two planes per packed
+                    // instruction.  It may only err towards "met": the origin and 1/direction are
+                    // rounded to single precision and every operation rounds once, which moves a plane
+                    // by less than 4 * 2^-24 * (|origin| + |plane| + inflation) and scales a ray
+                    // parameter by less than 1 +- 3 * 2^-24; the inflation is therefore enlarged by
+                    // 16 * 2^-24 * (|origin|_1 + largest |coordinate| of the scene) and the interval
+                    // test is relaxed by 1e-6 relative.  A direction component of (nearly) zero has
+                    // 1/direction = 1e300 -> inf here: the products become -inf/+inf on the two sides of
+                    // the origin (or NaN, which min/max drop), so that axis only asks "origin inside".
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const float sf[3] = {(float)a.x, (float)a.y, (float)b.x}, ivf[3] = {(float)b.y, (float)c.x, (float)c.y};
+                    const float mt = mg + S.fslack + 9.6e-7f * (fabsf(sf[0]) + fabsf(sf[1]) + fabsf(sf[2]));
+                    const float base[3] = {__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)};
+                    const float step[3] = {__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)};
+                    const unsigned qw[6] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w}; // 24 plane bytes: [child][axis][lower, upper]
                     const unsigned item[4] = {it.x, it.y, it.z, it.w};
+                    f2 cc[3], iv[3], st2[3], bs[3];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        cc[i] = (f2){sf[i] + mt, sf[i] - mt}; // lower planes move down by mt, upper planes up
+                        iv[i] = (f2){ivf[i], ivf[i]};
+                        st2[i] = (f2){step[i], step[i]};
+                        bs[i] = (f2){base[i], base[i]};
+                    }
                     bool hit[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        double tmin = 0.0, tmax = 1e300;
+                        float ta[3], tb[3];
 #pragma unroll
                         for (int i = 0; i < 3; i++) {
-                            const double t1 = __builtin_fma((double)lo[k][i], inv[i], A[i]), t2 = __builtin_fma((double)hi[k][i], inv[i], B[i]);
-                            tmin = fmax(tmin, fmin(t1, t2));
-                            tmax = fmin(tmax, fmax(t1, t2));
+                            const int bi = (k * 3 + i) * 2; // byte index of the lower plane
+                            const unsigned wd = qw[bi >> 2];
+                            const f2 qf = (bi & 2) ? (f2){(float)((wd >> 16) & 0xFFu), (float)(wd >> 24)} : (f2){(float)(wd & 0xFFu), (float)((wd >> 8) & 0xFFu)};
+                            const f2 pl = __builtin_elementwise_fma(qf, st2[i], bs[i]); // the two planes, exactly as the builder evaluated them
+                            const f2 t = (pl - cc[i]) * iv[i];
+                            ta[i] = fminf(t.x, t.y);
+                            tb[i] = fmaxf(t.x, t.y);
                         }
-                        hit[k] = (tmin <= tmax) & (item[k] != 0);
+                        const float tmin = fmaxf(fmaxf(ta[0], ta[1]), fmaxf(ta[2], 0.0f)), tmax = fminf(fminf(tb[0], tb[1]), tb[2]);
+                        hit[k] = (tmin * 0.999999f <= tmax) & (item[k] != 0);
                     }
                     // the first child that is met continues, the others go on the stack
                     const int n1 = hit[0], n2 = n1 + hit[1], n3 = n2 + hit[2], n4 = n3 + hit[3];
@@ -901,7 +925,7 @@ struct rt_scene {
     int dev = 0;
     DevScene d{};
     void *pool = nullptr, *tshade = nullptr, *sph = nullptr, *sshade = nullptr;
-    void *ovf = nullptr, *lstate = nullptr;
+    void *ovf = nullptr, *lstate = nullptr, *lhdr = nullptr;
     int tree_depth = 0;
     int grid = 0;               // persistent workgroups
     unsigned *d_counter = nullptr; // [0] block counter
@@ -974,35 +998,50 @@ void cull_fill(CullBuild &B, int a, int b, int depth, QuadRec &q, double lo[3], 
     if (b - mid >= 2) r[nr++] = cull_median(bt, mid, b);
     r[nr] = b;
     for (int k = 0; k < 3; k++) { lo[k] = 1e300; hi[k] = -1e300; }
-    for (int c = 0; c < 4; c++) {
-        q.item[c] = 0;
-        for (int k = 0; k < 3; k++) { q.lo[c][k] = 0; q.hi[c][k] = 0; }
-    }
+    double cl[4][3], ch[4][3];
+    memset(&q, 0, sizeof(q));
     for (int c = 0; c < nr; c++) {
         const int ca = r[c], cb = r[c + 1];
-        double l[3], h[3];
         if (cb - ca == 1) {
-            for (int k = 0; k < 3; k++) { l[k] = bt[ca].lo[k]; h[k] = bt[ca].hi[k]; }
+            for (int k = 0; k < 3; k++) { cl[c][k] = bt[ca].lo[k]; ch[c][k] = bt[ca].hi[k]; }
             q.item[c] = IT_TRI | (B.tri_base + 5u * (unsigned)(B.first + ca));
         } else {
             const size_t me = B.out->size();
             B.out->emplace_back();
             QuadRec sub;
-            memset(&sub, 0, sizeof(sub));
-            cull_fill(B, ca, cb, depth + 1, sub, l, h);
+            cull_fill(B, ca, cb, depth + 1, sub, cl[c], ch[c]);
             (*B.out)[me] = sub;
-            q.item[c] = IT_CULL | (B.cull_base + 8u * (unsigned)me);
+            q.item[c] = IT_CULL | (B.cull_base + 4u * (unsigned)me);
         }
-        for (int k = 0; k < 3; k++) {
-            q.lo[c][k] = f_down(l[k]); q.hi[c][k] = f_up(h[k]);
-            lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]);
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], cl[c][k]); hi[k] = std::max(hi[k], ch[c][k]); }
+    }
+    // quantise: bytes chosen against the device's own expression fmaf(byte, step, base)
+    for (int k = 0; k < 3; k++) {
+        const float base = f_down(lo[k]), top = f_up(hi[k]);
+        // 255 * step + base must reach `top` before rounding; then the rounded value is >= top >= hi
+        float step = f_up(((double)top - (double)base) / 255.0);
+        if (!(step >= 0.0f) || !std::isfinite(step)) step = 0.0f;
+        for (int guard = 0; guard < 8 && step > 0.0f && (double)fmaf(255.0f, step, base) < hi[k]; guard++)
+            step = std::nextafterf(step, INFINITY);
+        q.base[k] = base; q.step[k] = step;
+        for (int c = 0; c < nr; c++) {
+            int b0 = 0, b1 = 255;
+            if (step > 0.0f) {
+                b0 = (int)std::floor((cl[c][k] - (double)base) / (double)step);
+                b0 = std::max(0, std::min(255, b0));
+                while (b0 > 0 && (double)fmaf((float)b0, step, base) > cl[c][k]) b0--;
+                b1 = (int)std::ceil((ch[c][k] - (double)base) / (double)step);
+                b1 = std::max(0, std::min(255, b1));
+                while (b1 < 255 && (double)fmaf((float)b1, step, base) < ch[c][k]) b1++;
+            } else { b0 = 0; b1 = 0; } // a flat union box: every plane is `base` itself (hi == lo == base is checked below)
+            q.q[c][k][0] = (unsigned char)b0; q.q[c][k][1] = (unsigned char)b1;
         }
     }
 }
 
 // fills the list record of a list longer than SMALL_LIST and permutes order[first..first+count)
 void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<QuadRec> &cull, unsigned cull_base,
-                unsigned tri_base, QuadRec &li, int &max_depth) {
+                unsigned tri_base, QuadRec &li, ListHdr &hdr, int &max_depth) {
     std::vector<CullTri> bt((size_t)count);
     double lmax2 = 0;
     for (int j = 0; j < count; j++) {
@@ -1027,7 +1066,7 @@ void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &
     for (int j = 0; j < count; j++) order[first + j] = bt[j].src;
     float kf = f_up(2.0 * (1e-9 * lmax2 + 1e-10) * 1.000001); // the list's margin coefficient, rounded up
     if (!(kf >= 0.0f)) kf = INFINITY;
-    memcpy(&li.meta, &kf, 4);
+    memcpy(&hdr.meta, &kf, 4);
 }
 
 int validate(const rt_scene_desc *D) {
@@ -1191,16 +1230,17 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (dev < 0 || dev >= ndev) return fail(RT_E_INVALID, "device %d not in [0,%d)", dev, ndev);
     HIP_TRY(hipSetDevice(dev));
 
-    // pool layout in 16-byte granules: nodes (4 each), their list records (8 each), cull records (8), triangles (5)
+    // pool layout in 16-byte granules: nodes (4 each), their list records (4 each), cull records (4), triangles (5)
     size_t n_cull = 0;
     for (int i = 0; i < D->n_nodes; i++)
         if (D->node_count[i] > SMALL_LIST) n_cull += quad_count(D->node_count[i]) - 1; // records below the root
-    const size_t g_list = (4 * (size_t)D->n_nodes + 7) / 8 * 8, g_cull = g_list + 8 * (size_t)D->n_nodes, g_tri = g_cull + 8 * n_cull,
+    const size_t g_list = 4 * (size_t)D->n_nodes, g_cull = g_list + 4 * (size_t)D->n_nodes, g_tri = g_cull + 4 * n_cull,
                  g_end = g_tri + 5 * (size_t)D->n_tris + 3;
     if (g_end > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
     std::vector<char> pool(g_end * 16, 0);
     std::vector<QuadRec> cull;
     cull.reserve(n_cull);
+    std::vector<ListHdr> lhdr((size_t)D->n_nodes);
     std::vector<int> order((size_t)D->n_list); // device position -> entry of list_tri
     for (int i = 0; i < D->n_list; i++) order[i] = i;
     int cull_depth = 0;
@@ -1212,15 +1252,16 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         n.info = (unsigned)D->node_axis[i] | (D->node_left[i] >= 0 ? 4u : 0u) | ((unsigned)D->node_count[i] << 3);
         QuadRec li;
         memset(&li, 0, sizeof(li));
+        ListHdr &hdr = lhdr[i];
         const int cnt = D->node_count[i], first = D->node_first[i];
-        if (cnt > SMALL_LIST) build_list(D, first, cnt, order, cull, (unsigned)g_cull, (unsigned)g_tri, li, cull_depth);
+        if (cnt > SMALL_LIST) build_list(D, first, cnt, order, cull, (unsigned)g_cull, (unsigned)g_tri, li, hdr, cull_depth);
         else {
-            li.meta = LIST_SHORT | (unsigned)cnt;
+            hdr.meta = LIST_SHORT | (unsigned)cnt;
             li.item[0] = IT_TRI | IT_CHAIN | ((unsigned)g_tri + 5u * (unsigned)first);
         }
-        li.right = n.right;
+        hdr.right = n.right;
         memcpy(&pool[(size_t)i * 64], &n, 64);
-        memcpy(&pool[(g_list + 8 * (size_t)i) * 16], &li, 128);
+        memcpy(&pool[(g_list + 4 * (size_t)i) * 16], &li, 64);
     }
     if (cull.size() != n_cull) return fail(RT_E_INVALID, "internal: culling hierarchy size mismatch");
     if (n_cull) memcpy(&pool[g_cull * 16], cull.data(), n_cull * sizeof(QuadRec));
@@ -1274,6 +1315,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->dev = dev;
     s->tree_depth = D->tree_depth;
     rc = upload(&s->pool, pool);
+    if (!rc) rc = upload(&s->lhdr, lhdr);
     if (!rc) rc = upload(&s->tshade, tsh);
     if (!rc) rc = upload(&s->sph, sg);
     if (!rc) rc = upload(&s->sshade, ss);
@@ -1331,6 +1373,8 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     }
     s->d.padc = 2.5e-5 + 4e-12 * boxsum;
     s->d.g_list = (unsigned)g_list;
+    s->d.lhdr = (const ListHdr *)s->lhdr;
+    s->d.fslack = f_up(16.0 * 5.97e-8 * (s->d.absn + s->d.reach)); // see the cull step
     s->d.n_sph = D->n_spheres;
     s->d.ovf_depth = ovf_depth;
     s->d.n_slots = n_slots;
@@ -1341,7 +1385,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->d_counter, s->d_stats, s->d_tiles};
+    void *ptrs[] = {s->pool, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_stats, s->d_tiles};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
