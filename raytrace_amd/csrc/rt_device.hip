@@ -67,7 +67,11 @@ constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE; // ray slots per lane of the own
 constexpr int SLOTS = WAVE * RAYS_PER_LANE; // ray slots per workgroup
 constexpr int LDS_STACK = RT_LDS_STACK; // the newest traversal-stack levels are kept in LDS (a ring, a power of two), older ones in HBM
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
+#ifdef RT_PROFILE
+constexpr int N_STATS = 23; // 9..18: clock ticks in vote, the four bodies, tail; steps per kind; 19..22: triangle step details
+#else
 constexpr int N_STATS = 9;
+#endif
 constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly, longer ones get a hierarchy
 
 // Every traversal record lives in ONE pool addressed in 16-byte granules, and a work item carries
@@ -360,15 +364,22 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     __shared__ double2 sA[SLOTS]; // origin x, y
     __shared__ double2 sB[SLOTS]; // origin z, 1/direction x
     __shared__ double2 sC[SLOTS]; // 1/direction y, z
-    __shared__ uint2 sW[SLOTS];   // current item; flags word
     __shared__ float sM[SLOTS];   // inflation of the current list's culling boxes
     __shared__ float sG[SLOTS];   // the ray's margin factor
     __shared__ unsigned sL[SLOTS]; // current list (node granule)
     __shared__ unsigned stk[LDS_STACK][SLOTS];
-    __shared__ uint2 sQ[WAVE];    // this iteration's lane -> slot assignment: slot | flags word << 8; item
+    // the slots that wait for a step, one stack per kind: slot | flags word << 8; item.  Two stacks share an
+    // array and grow towards each other (a slot is in at most one of them): node up from 0 and cull down from
+    // SLOTS - 1, tri up from SLOTS and shade down from 2 * SLOTS - 1
+    __shared__ uint2 sQ[2 * SLOTS];
     static_assert(SLOTS <= 256, "a slot index is kept in 8 bits");
+#ifdef RT_LDS_PAD // occupancy experiments: unused LDS that the compiler cannot drop
+    __shared__ unsigned lds_pad[RT_LDS_PAD / 4];
+    if (n_work == 0xFFFFFFFFu) { lds_pad[threadIdx.x] = n_work; __syncthreads(); n_work = lds_pad[threadIdx.x ^ 1]; }
+#endif
     const int lane = threadIdx.x;
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    auto qindex = [](int kind, int i) __attribute__((always_inline)) { return (kind >> 1) * SLOTS + ((kind & 1) ? SLOTS - 1 - i : i); };
     const size_t lss = (size_t)S.n_slots;
     const unsigned gslot0 = blockIdx.x * SLOTS;
 
@@ -376,9 +387,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
 #pragma unroll
     for (int r = 0; r < RAYS_PER_LANE; r++) {
         S.lstate[LS_PST * lss + gslot0 + lane + r * WAVE] = 0.0;
-        sW[lane + r * WAVE] = make_uint2(0u, (unsigned)K_SHADE << ST_KIND);
+        sQ[qindex(K_SHADE, lane + r * WAVE)] = make_uint2((unsigned)(lane + r * WAVE), 0u);
     }
-    unsigned flip = 0; // alternates which half of the slots is handed out first
+    int q0 = 0, q1 = 0, q2 = 0, q3 = SLOTS; // entries on the four stacks
     // work counters: wavefront-uniform 32-bit sums of lane counts in scalar registers, flushed to
     // the 64-bit totals in HBM long before they can overflow; only the own-list lengths need a
     // per-lane sum
@@ -400,47 +411,27 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
 
     const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
 
+#ifdef RT_PROFILE
+    unsigned long long p_vote = 0, p_body[4] = {0, 0, 0, 0}, p_tail = 0, p_n[4] = {0, 0, 0, 0}, p_tri[4] = {0, 0, 0, 0};
+#define RT_TICK(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#else
+#define RT_TICK(x)
+#endif
     for (;;) {
-        // ---- vote: run the kind most slots wait for; lane l looks at slots l, l + 64, ...
-        uint2 w[RAYS_PER_LANE];
-        unsigned kd[RAYS_PER_LANE];
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-        for (int r = 0; r < RAYS_PER_LANE; r++) {
-            w[r] = sW[lane + r * WAVE];
-            kd[r] = (w[r].y >> ST_KIND) & 7u;
-            c0 += __popcll(__ballot(kd[r] == K_NODE)); c1 += __popcll(__ballot(kd[r] == K_CULL));
-            c2 += __popcll(__ballot(kd[r] == K_TRI)); c3 += __popcll(__ballot(kd[r] == K_SHADE));
-        }
-        asm("" : "+s"(c0), "+s"(c1), "+s"(c2), "+s"(c3)); // keep the comparison below in 32-bit scalar registers
-        int pick = K_NODE, most = c0;
-        if (c1 > most) { most = c1; pick = K_CULL; }
-        if (c2 > most) { most = c2; pick = K_TRI; }
-        if (c3 > most) { most = c3; pick = K_SHADE; }
+        RT_TICK(tk0);
+        // ---- vote: run the kind most slots wait for; its (up to 64) topmost entries go to the lanes
+        asm("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3)); // keep the counts in scalar registers
+        int pick = K_NODE, most = q0;
+        if (q1 > most) { most = q1; pick = K_CULL; }
+        if (q2 > most) { most = q2; pick = K_TRI; }
+        if (q3 > most) { most = q3; pick = K_SHADE; }
         if (most == 0) break; // every slot is done
-        // ---- hand the slots of that kind to the lanes in slot order; the direction alternates so
-        // that no group of slots is always served last
-        flip ^= 1u;
-        unsigned nin[RAYS_PER_LANE], tot = 0;
-        unsigned long long min_[RAYS_PER_LANE];
-#pragma unroll
-        for (int r = 0; r < RAYS_PER_LANE; r++) {
-            min_[r] = __ballot(kd[r] == (unsigned)pick);
-            nin[r] = (unsigned)__popcll(min_[r]);
-            tot += nin[r];
-        }
-        unsigned before = 0; // slots of the kind in the groups below r
-#pragma unroll
-        for (int r = 0; r < RAYS_PER_LANE; r++) {
-            const unsigned base = flip ? tot - before - nin[r] : before;
-            const unsigned pos = base + (unsigned)__popcll(min_[r] & lane_lt);
-            if (kd[r] == (unsigned)pick && pos < (unsigned)WAVE) sQ[pos] = make_uint2((unsigned)(lane + r * WAVE) | (w[r].y << 8), w[r].x);
-            before += nin[r];
-        }
         const int nrun = most < WAVE ? most : WAVE;
+        const int rest = most - nrun;
+        if (pick == K_NODE) q0 = rest; else if (pick == K_CULL) q1 = rest; else if (pick == K_TRI) q2 = rest; else q3 = rest;
         const bool run = lane < nrun;
         uint2 e = make_uint2(0u, 0u);
-        if (run) e = sQ[lane];
+        if (run) e = sQ[qindex(pick, rest + lane)];
         const int slot = (int)(e.x & 0xFFu);
         const unsigned cur = e.y;
         unsigned st = e.x >> 8;
@@ -463,6 +454,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         unsigned next = 0;      // otherwise: the item to continue with
         unsigned push_item = 0; // item to push before that (0 = none; the root is never pushed)
         bool done = false;      // the slot found no more work
+        RT_TICK(tk1);
 
         if (pick == K_NODE) {
             if (run) { // ---- enter a node (kdtree.cpp:111-141)
@@ -646,6 +638,12 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 }
                 if ((cur & IT_CHAIN) && !((unsigned)w9 & TRI_LAST)) next = cur + 5u; // the list's next triangle
                 else want_pop = true;
+#ifdef RT_PROFILE
+                p_tri[0] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) != 0));          // tests of short lists
+                p_tri[1] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) != 0 && t > EPS)); // ... that hit
+                p_tri[2] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) == 0));          // tests behind culling boxes
+                p_tri[3] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) == 0 && t > EPS)); // ... that hit
+#endif
             }
             RT_SCOUNT(c_done, nrun);
         } else {
@@ -868,6 +866,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         }
 
         // ---- common tail for the lanes that ran: push, pop, publish the slot's next item
+        RT_TICK(tk2);
         if (run) {
             if (push_item != 0) push(push_item);
             if (want_pop) {
@@ -881,10 +880,31 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     }
                 }
             }
-            const unsigned nk = done ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
-            sW[slot] = make_uint2(next == IT_END ? 0u : next, (st & ST_FLAG) | (unsigned)sp | (nk << ST_KIND) | ((unsigned)slo << ST_LO));
         }
+        // the slot goes on the stack of the kind of step it needs next
+        {
+            const unsigned nk = (!run || done) ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
+            const unsigned long long m0 = __ballot(nk == K_NODE), m1 = __ballot(nk == K_CULL), m2 = __ballot(nk == K_TRI), m3 = __ballot(nk == K_SHADE);
+            const unsigned long long mine = nk == K_NODE ? m0 : nk == K_CULL ? m1 : nk == K_TRI ? m2 : m3;
+            const int below = nk == K_NODE ? q0 : nk == K_CULL ? q1 : nk == K_TRI ? q2 : q3;
+            const int at = below + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
+            if (nk != K_DONE)
+                sQ[qindex((int)nk, at)] = make_uint2((unsigned)slot | (((st & ST_FLAG) | (unsigned)sp | ((unsigned)slo << ST_LO)) << 8), next == IT_END ? 0u : next);
+            q0 += __popcll(m0); q1 += __popcll(m1); q2 += __popcll(m2); q3 += __popcll(m3);
+        }
+#ifdef RT_PROFILE
+        RT_TICK(tk3);
+        p_vote += tk1 - tk0; p_tail += tk3 - tk2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (pick == k) { p_body[k] += tk2 - tk1; p_n[k]++; }
+#endif
     }
+#ifdef RT_PROFILE
+    if (lane == 0) {
+        atomicAdd(gstats + 9, p_vote); atomicAdd(gstats + 14, p_tail);
+        for (int k = 0; k < 4; k++) { atomicAdd(gstats + 10 + k, p_body[k]); atomicAdd(gstats + 15 + k, p_n[k]); atomicAdd(gstats + 19 + k, p_tri[k]); }
+    }
+#endif
 
     // ---- work counters
     flush();
@@ -1410,6 +1430,20 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
     HIP_TRY(hipMemset(s->d_stats, 0, sizeof(h)));
     stats->rays = h[0]; stats->node_visits = h[1]; stats->tri_tests = h[2]; stats->sph_tests = h[3]; stats->tri_shades = h[4];
     stats->tri_tests_done = h[5]; stats->cull_tests = h[6]; stats->sched_steps = h[7]; stats->sched_lanes = h[8];
+#ifdef RT_PROFILE
+    {
+        static const char *kn[4] = {"node", "cull", "tri", "shade"};
+        const double steps = (double)(h[15] + h[16] + h[17] + h[18]);
+        if (steps > 0) {
+            fprintf(stderr, "[profile] steps %.0f  ticks/step: vote %.1f tail %.1f\n", steps, h[9] / steps, h[14] / steps);
+            for (int k = 0; k < 4; k++)
+                fprintf(stderr, "[profile]   %-5s steps %5.1f%%  body ticks/step %.1f  share of ticks %.1f%%\n", kn[k], 100.0 * h[15 + k] / steps,
+                        h[15 + k] ? (double)h[10 + k] / h[15 + k] : 0.0, 100.0 * h[10 + k] / (double)(h[9] + h[14] + h[10] + h[11] + h[12] + h[13]));
+            fprintf(stderr, "[profile]   triangle tests per ray: short lists %.1f (hit %.2f), behind boxes %.1f (hit %.2f)\n", (double)h[19] / h[0],
+                    (double)h[20] / h[0], (double)h[21] / h[0], (double)h[22] / h[0]);
+        }
+    }
+#endif
     return RT_OK;
 }
 
