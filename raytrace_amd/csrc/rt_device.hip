@@ -356,6 +356,8 @@ constexpr int ST_KIND = 9, ST_LO = 12;
 // TRACE = false: slots pull pixels (8x8 blocks, one slot per pixel) from an atomic counter and
 // run each pixel's 4*samps paths in the reference's order.  TRACE = true: slots pull explicit rays
 // and report the nearest triangle / sphere (raytrace.cpp:46-47).
+__device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30f), 1e30f); }
+
 template <bool TRACE>
 __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCamera cam, rt_params P, const DevTile *tiles, int n_tiles,
                                                              unsigned n_work, unsigned *counter, double *rgb, int *prim,
@@ -478,25 +480,25 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 //    loop accepts on that axis.
                 // Whatever is left (grazing rays, nearly axis-parallel directions) runs the exact code.
                 const double pad = S.padc + 4e-12 * (fabs(s[0]) + fabs(s[1]) + fabs(s[2]));
-                double tin = -1e300, tout = 1e300, tinp = 0.0, toutp = 1e300, imax = 0.0;
+                double tin = -1e300, tout = 1e300, imax = 0.0;
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
                     const double t1 = (mi[i] - s[i]) * inv[i], t2 = (ma[i] - s[i]) * inv[i];
-                    const double ta = fmin(t1, t2), tb = fmax(t1, t2), pi = pad * fabs(inv[i]);
-                    tin = fmax(tin, ta); tout = fmin(tout, tb);
-                    tinp = fmax(tinp, ta - pi); toutp = fmin(toutp, tb + pi);
+                    tin = fmax(tin, fmin(t1, t2)); tout = fmin(tout, fmax(t1, t2));
                     imax = fmax(imax, fabs(inv[i]));
                 }
-                const bool maybe = tinp <= toutp;
+                // growing the box by `pad` moves every slab parameter by at most pad * max|1/direction|
+                const double pm = pad * imax;
+                const bool maybe = (tin - pm <= tout + pm) & (tout + pm >= 0.0);
                 const bool inside = (mi[0] < s[0] + EPS) & (s[0] < ma[0] + EPS) & (mi[1] < s[1] + EPS) & (s[1] < ma[1] + EPS) &
                                     (mi[2] < s[2] + EPS) & (s[2] < ma[2] + EPS);
                 const bool clear = (tin <= tout) & (tin > 2e-5) & (imax < 4e4) & (pad < 3e-5);
                 const int axis = info & 3;
                 const double sw = axis == 0 ? s[0] : axis == 1 ? s[1] : s[2];
                 const double iw = axis == 0 ? inv[0] : axis == 1 ? inv[1] : inv[2];
-                bool pass = maybe & (inside | clear);
+                bool pass = inside | clear;
                 bool vpos = iw > 0, vneg = iw < 0; // sign of the direction along the split axis
-                if ((maybe & !inside & !clear) | (fabs(iw) >= 1e299)) { // rare: needs the direction itself
+                if ((maybe & !pass) | (fabs(iw) >= 1e299)) { // rare: needs the direction itself
                     const double v[3] = {ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]};
                     if (!pass) pass = maybe && aabb_hit(mi, ma, s, v);
                     const double vw = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
@@ -550,28 +552,33 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 }
                 if (boxes) {
                     // Slab test of the four inflated boxes in single precision, two planes per packed
-                    // instruction.  It may only err towards "met": the origin and 1/direction are
-                    // rounded to single precision and every operation rounds once, which moves a plane
-                    // by less than 4 * 2^-24 * (|origin| + |plane| + inflation) and scales a ray
-                    // parameter by less than 1 +- 3 * 2^-24; the inflation is therefore enlarged by
-                    // 16 * 2^-24 * (|origin|_1 + largest |coordinate| of the scene) and the interval
-                    // test is relaxed by 1e-6 relative.  A direction component of (nearly) zero has
-                    // 1/direction = 1e300 -> inf here: the products become -inf/+inf on the two sides of
-                    // the origin (or NaN, which min/max drop), so that axis only asks "origin inside".
+                    // instruction: the ray parameter of the plane base + q * step is evaluated as
+                    // q * (step / d) + (base - origin -+ m) / d, one fma per pair of planes.  It may only
+                    // err towards "met".  Against the plane the builder verified (the single-precision
+                    // fma(q, step, base), within half an ulp of base + q * step) the rounding of the
+                    // origin, of the three products, of the two differences and of the fma moves a plane
+                    // by less than 2^-24 * (10 C + 5.1 |origin| + 4.1 m), C = largest |coordinate| of the
+                    // scene; the inflation m is therefore enlarged by 16 * 2^-24 * (|origin|_1 + C) and by
+                    // 1e-6 of itself.  Rounding 1/direction scales all parameters of an axis by
+                    // 1 +- 2^-24, for which the interval test is relaxed by 1e-6 relative.  1/direction
+                    // is limited to +-1e30 (a direction component of zero has 1e300 there) so that every
+                    // product stays finite: on such an axis the parameters are then beyond +-1e18 unless
+                    // the origin lies exactly on a moved plane, far outside the parameters of the other
+                    // axes (directions are at least 1e-10 long), which is all the test needs of them.
                     typedef float f2 __attribute__((ext_vector_type(2)));
-                    const float sf[3] = {(float)a.x, (float)a.y, (float)b.x}, ivf[3] = {(float)b.y, (float)c.x, (float)c.y};
-                    const float mt = mg + S.fslack + 9.6e-7f * (fabsf(sf[0]) + fabsf(sf[1]) + fabsf(sf[2]));
+                    const float sf[3] = {(float)a.x, (float)a.y, (float)b.x}, ivf[3] = {cull_inv((float)b.y), cull_inv((float)c.x), cull_inv((float)c.y)};
+                    const float mt = (mg + S.fslack + 9.6e-7f * (fabsf(sf[0]) + fabsf(sf[1]) + fabsf(sf[2]))) * 1.000001f;
                     const float base[3] = {__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)};
                     const float step[3] = {__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)};
                     const unsigned qw[6] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w}; // 24 plane bytes: [child][axis][lower, upper]
                     const unsigned item[4] = {it.x, it.y, it.z, it.w};
-                    f2 cc[3], iv[3], st2[3], bs[3];
+                    f2 ka[3], kb[3]; // ray parameter of the plane with byte q: q * ka + kb
 #pragma unroll
                     for (int i = 0; i < 3; i++) {
-                        cc[i] = (f2){sf[i] + mt, sf[i] - mt}; // lower planes move down by mt, upper planes up
-                        iv[i] = (f2){ivf[i], ivf[i]};
-                        st2[i] = (f2){step[i], step[i]};
-                        bs[i] = (f2){base[i], base[i]};
+                        const float a1 = step[i] * ivf[i];
+                        ka[i] = (f2){a1, a1};
+                        // lower planes move down by mt, upper planes up
+                        kb[i] = (f2){(base[i] - (sf[i] + mt)) * ivf[i], (base[i] - (sf[i] - mt)) * ivf[i]};
                     }
                     bool hit[4];
 #pragma unroll
@@ -582,8 +589,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                             const int bi = (k * 3 + i) * 2; // byte index of the lower plane
                             const unsigned wd = qw[bi >> 2];
                             const f2 qf = (bi & 2) ? (f2){(float)((wd >> 16) & 0xFFu), (float)(wd >> 24)} : (f2){(float)(wd & 0xFFu), (float)((wd >> 8) & 0xFFu)};
-                            const f2 pl = __builtin_elementwise_fma(qf, st2[i], bs[i]); // the two planes, exactly as the builder evaluated them
-                            const f2 t = (pl - cc[i]) * iv[i];
+                            const f2 t = __builtin_elementwise_fma(qf, ka[i], kb[i]);
                             ta[i] = fminf(t.x, t.y);
                             tb[i] = fmaxf(t.x, t.y);
                         }
