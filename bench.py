@@ -28,7 +28,7 @@ B_NODE = 72   # box 48 + split 8 + axis/children/list range 16, per KdTree::chec
 B_TRI = 72    # three FP64 vertices, per Polygon::intersect
 B_SHADE = 76  # nc, col, lig, type, per shaded triangle hit
 B_SPH = 32    # centre + radius, per Sphere::intersect
-B_CULL = 112  # four single-precision boxes 96 + four links 16, per culling record visited (long own lists)
+B_CULL = 64   # base and step 24 + 24 plane bytes of four boxes + four links 16, per culling record visited (long own lists)
 # FP64 operation counts per unit of work (adds/multiplies/compares; divides and sqrt counted once)
 F_NODE, F_TRI, F_SPH, F_SHADE, F_CULL = 40, 45, 20, 100, 96
 HBM_PEAK_GBS = 8000.0

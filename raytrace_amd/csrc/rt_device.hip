@@ -316,6 +316,10 @@ constexpr unsigned IT_CULL = 1u << 29, IT_TRI = 2u << 29, IT_CHAIN = 1u << 28, I
                    IDX28 = 0x0FFFFFFFu;
 constexpr unsigned TRI_LAST = 0x80000000u; // in TriRec::pos: last triangle of its own list
 constexpr unsigned IT_END = 0xFFFFFFFFu; // "the stack is empty": the traversal is complete
+// A node-kind item no node can have: "the next stack levels are in HBM".  The step that runs it fetches
+// them together with the other lanes' node records instead of making the popping step wait for HBM.
+constexpr unsigned IT_REFILL = 0x1FFFFFFFu;
+constexpr int REFILL = LDS_STACK >= 8 ? 4 : LDS_STACK >= 4 ? 2 : 1; // levels fetched at once
 enum { K_NODE = 0, K_CULL = 1, K_TRI = 2, K_SHADE = 3, K_DONE = 4 };
 enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, ST_ITERS, ST_LANES };
 // Words of a ray slot's state kept in HBM (8 bytes each, [word][slot] so lanes coalesce): what
@@ -459,7 +463,16 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         RT_TICK(tk1);
 
         if (pick == K_NODE) {
-            if (run) { // ---- enter a node (kdtree.cpp:111-141)
+            const bool refill = run && cur == IT_REFILL;
+            unsigned rf[REFILL];
+            if (refill) { // issue the loads of levels sp - 1 (the item to continue with), sp - 2, ...
+#pragma unroll
+                for (int k = 0; k < REFILL; k++) {
+                    const int lv = sp - 1 - k > 0 ? sp - 1 - k : 0;
+                    rf[k] = S.ovf[(unsigned)lv * (unsigned)S.n_slots + gslot0 + (unsigned)slot];
+                }
+            }
+            if (run && !refill) { // ---- enter a node (kdtree.cpp:111-141)
                 const double2 *p = (const double2 *)(S.pool + (size_t)cur * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
@@ -522,7 +535,15 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     else next = after;
                 }
             }
-            RT_SCOUNT(c_visits, nrun);
+            if (refill) { // levels [slo', sp - 1) go to the ring, level sp - 1 continues
+                sp--;
+                next = rf[0];
+#pragma unroll
+                for (int k = 1; k < REFILL; k++)
+                    if (sp - k >= 0) stk[(sp - k) & (LDS_STACK - 1)][slot] = rf[k];
+                slo = sp - (REFILL - 1) > 0 ? sp - (REFILL - 1) : 0;
+            }
+            RT_SCOUNT(c_visits, nrun - (int)__popcll(__ballot(refill)));
         } else if (pick == K_CULL) {
             bool boxes = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
@@ -601,7 +622,16 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     if (n4 == 0) want_pop = true;
                     else {
                         next = hit[0] ? item[0] : hit[1] ? item[1] : hit[2] ? item[2] : item[3];
-                        if (sp - slo + 3 <= LDS_STACK) { // the usual case: room for all three in the ring
+                        if (LDS_STACK >= 4 || sp - slo + 3 <= LDS_STACK) {
+                            if (LDS_STACK >= 4) { // make room first: the oldest levels move to HBM
+                                const int over = sp - slo + (n4 - 1) - LDS_STACK;
+                                if (over > 0) {
+#pragma unroll
+                                    for (int k = 0; k < 3; k++)
+                                        if (k < over) S.ovf[(unsigned)(slo + k) * (unsigned)S.n_slots + gslot0 + (unsigned)slot] = stk[(slo + k) & (LDS_STACK - 1)][slot];
+                                    slo += over;
+                                }
+                            }
                             if (hit[1] & (n1 > 0)) stk[(sp + n1 - 1) & (LDS_STACK - 1)][slot] = item[1];
                             if (hit[2] & (n2 > 0)) stk[(sp + n2 - 1) & (LDS_STACK - 1)][slot] = item[2];
                             if (hit[3] & (n3 > 0)) stk[(sp + n3 - 1) & (LDS_STACK - 1)][slot] = item[3];
@@ -880,9 +910,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 else {
                     sp--;
                     if (sp >= slo) next = stk[sp & (LDS_STACK - 1)][slot];
-                    else { // the ring is empty: the level is in HBM
-                        slo = sp;
-                        next = S.ovf[(unsigned)sp * (unsigned)S.n_slots + gslot0 + (unsigned)slot];
+                    else { // the ring is empty: the level is in HBM and stays there until a refill step
+                        sp++;
+                        next = IT_REFILL;
                     }
                 }
             }
