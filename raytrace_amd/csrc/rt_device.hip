@@ -61,7 +61,7 @@ constexpr int WAVE = 64;          // threads per workgroup: one wavefront
 #define RT_RAYS_PER_LANE 2
 #endif
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 16
+#define RT_LDS_STACK 8
 #endif
 constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE; // ray slots per lane of the owning wavefront
 constexpr int SLOTS = WAVE * RAYS_PER_LANE; // ray slots per workgroup
