@@ -1015,23 +1015,60 @@ struct CullBuild {
     int max_depth;
 };
 
-// number of records the hierarchy of a range of n >= 2 triangles takes (the splits depend on n only)
-size_t quad_count(int n) {
-    size_t k = 1;
-    const int h[2] = {n / 2, n - n / 2};
-    for (int i = 0; i < 2; i++) {
-        if (h[i] < 2) continue;
-        const int q[2] = {h[i] / 2, h[i] - h[i] / 2};
-        for (int j = 0; j < 2; j++)
-            if (q[j] >= 2) k += quad_count(q[j]);
-    }
-    return k;
-}
-
-int cull_median(std::vector<CullTri> &bt, int a, int b) { // partitions [a, b) around its median, returns the split point
+// Splits the range [a, b) (b - a >= 2) in two and returns the split point: the plane between 16
+// centroid bins, over the three axes, with the smallest sum of (surface area of the part's box) *
+// (triangles in the part); the median along the widest axis where the centroids do not separate.
+int cull_split(std::vector<CullTri> &bt, int a, int b) {
     double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
     for (int i = a; i < b; i++)
         for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], bt[i].c[k]); chi[k] = std::max(chi[k], bt[i].c[k]); }
+    constexpr int NB = 16;
+    double best = 1e300, best_plane = 0;
+    int best_ax = -1;
+    if (b - a > 2) {
+        for (int ax = 0; ax < 3; ax++) {
+            const double w = chi[ax] - clo[ax];
+            if (!(w > 0)) continue;
+            struct Bin { double lo[3], hi[3]; int n; } bin[NB];
+            for (int j = 0; j < NB; j++) { bin[j].n = 0; for (int k = 0; k < 3; k++) { bin[j].lo[k] = 1e300; bin[j].hi[k] = -1e300; } }
+            const double sc = NB / w;
+            for (int i = a; i < b; i++) {
+                int j = (int)((bt[i].c[ax] - clo[ax]) * sc);
+                j = j < 0 ? 0 : j >= NB ? NB - 1 : j;
+                bin[j].n++;
+                for (int k = 0; k < 3; k++) { bin[j].lo[k] = std::min(bin[j].lo[k], bt[i].lo[k]); bin[j].hi[k] = std::max(bin[j].hi[k], bt[i].hi[k]); }
+            }
+            double rarea[NB];
+            int rn[NB];
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            int n = 0;
+            auto area = [](const double *l, const double *h) {
+                const double x = h[0] - l[0], y = h[1] - l[1], z = h[2] - l[2];
+                return x * y + y * z + z * x;
+            };
+            for (int j = NB - 1; j > 0; j--) { // parts to the right of the plane below bin j
+                n += bin[j].n;
+                for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], bin[j].lo[k]); hi[k] = std::max(hi[k], bin[j].hi[k]); }
+                rn[j] = n; rarea[j] = n ? area(lo, hi) : 0.0;
+            }
+            for (int k = 0; k < 3; k++) { lo[k] = 1e300; hi[k] = -1e300; }
+            n = 0;
+            for (int j = 1; j < NB; j++) {
+                n += bin[j - 1].n;
+                for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], bin[j - 1].lo[k]); hi[k] = std::max(hi[k], bin[j - 1].hi[k]); }
+                if (n == 0 || rn[j] == 0) continue;
+                const double cost = area(lo, hi) * n + rarea[j] * rn[j];
+                if (cost < best) { best = cost; best_ax = ax; best_plane = clo[ax] + j / sc; }
+            }
+        }
+    }
+    if (best_ax >= 0) {
+        const int ax = best_ax;
+        const double plane = best_plane;
+        const auto it = std::partition(bt.begin() + a, bt.begin() + b, [ax, plane](const CullTri &x) { return x.c[ax] < plane; });
+        const int mid = (int)(it - bt.begin());
+        if (mid > a && mid < b) return mid;
+    }
     int ax = 0;
     if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
     if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
@@ -1047,11 +1084,11 @@ void cull_fill(CullBuild &B, int a, int b, int depth, QuadRec &q, double lo[3], 
     if (depth > B.max_depth) B.max_depth = depth;
     std::vector<CullTri> &bt = *B.bt;
     int r[5], nr = 0; // child range boundaries
-    const int mid = cull_median(bt, a, b);
+    const int mid = cull_split(bt, a, b);
     r[nr++] = a;
-    if (mid - a >= 2) r[nr++] = cull_median(bt, a, mid);
+    if (mid - a >= 2) r[nr++] = cull_split(bt, a, mid);
     r[nr++] = mid;
-    if (b - mid >= 2) r[nr++] = cull_median(bt, mid, b);
+    if (b - mid >= 2) r[nr++] = cull_split(bt, mid, b);
     r[nr] = b;
     for (int k = 0; k < 3; k++) { lo[k] = 1e300; hi[k] = -1e300; }
     double cl[4][3], ch[4][3];
@@ -1286,16 +1323,13 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (dev < 0 || dev >= ndev) return fail(RT_E_INVALID, "device %d not in [0,%d)", dev, ndev);
     HIP_TRY(hipSetDevice(dev));
 
-    // pool layout in 16-byte granules: nodes (4 each), their list records (4 each), cull records (4), triangles (5)
-    size_t n_cull = 0;
-    for (int i = 0; i < D->n_nodes; i++)
-        if (D->node_count[i] > SMALL_LIST) n_cull += quad_count(D->node_count[i]) - 1; // records below the root
-    const size_t g_list = 4 * (size_t)D->n_nodes, g_cull = g_list + 4 * (size_t)D->n_nodes, g_tri = g_cull + 4 * n_cull,
-                 g_end = g_tri + 5 * (size_t)D->n_tris + 3;
-    if (g_end > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
-    std::vector<char> pool(g_end * 16, 0);
+    // pool layout in 16-byte granules: nodes (4 each), their list records (4 each), triangles (5), cull records (4);
+    // how many cull records the hierarchies take is only known once they are built
+    const size_t g_list = 4 * (size_t)D->n_nodes, g_tri = g_list + 4 * (size_t)D->n_nodes,
+                 g_cull = (g_tri + 5 * (size_t)D->n_tris + 3) & ~(size_t)3;
+    if (g_cull + 4 > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
+    std::vector<char> pool(g_cull * 16, 0);
     std::vector<QuadRec> cull;
-    cull.reserve(n_cull);
     std::vector<ListHdr> lhdr((size_t)D->n_nodes);
     std::vector<int> order((size_t)D->n_list); // device position -> entry of list_tri
     for (int i = 0; i < D->n_list; i++) order[i] = i;
@@ -1319,7 +1353,10 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         memcpy(&pool[(size_t)i * 64], &n, 64);
         memcpy(&pool[(g_list + 4 * (size_t)i) * 16], &li, 64);
     }
-    if (cull.size() != n_cull) return fail(RT_E_INVALID, "internal: culling hierarchy size mismatch");
+    const size_t n_cull = cull.size();
+    const size_t g_end = g_cull + 4 * n_cull + 4;
+    if (g_end > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
+    pool.resize(g_end * 16, 0);
     if (n_cull) memcpy(&pool[g_cull * 16], cull.data(), n_cull * sizeof(QuadRec));
     std::vector<unsigned char> last((size_t)D->n_list, 0); // device position is the last of its own list
     for (int i = 0; i < D->n_nodes; i++)
