@@ -72,7 +72,10 @@ constexpr int N_STATS = 23; // 9..18: clock ticks in vote, the four bodies, tail
 #else
 constexpr int N_STATS = 9;
 #endif
-constexpr int SMALL_LIST = 4; // own lists up to this length are tested directly, longer ones get a hierarchy
+#ifndef RT_SMALL_LIST
+#define RT_SMALL_LIST 1
+#endif
+constexpr int SMALL_LIST = RT_SMALL_LIST; // own lists up to this length are tested directly, longer ones get a hierarchy
 
 // Every traversal record lives in ONE pool addressed in 16-byte granules, and a work item carries
 // the granule of its record:
@@ -1022,7 +1025,10 @@ int cull_split(std::vector<CullTri> &bt, int a, int b) {
     double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
     for (int i = a; i < b; i++)
         for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], bt[i].c[k]); chi[k] = std::max(chi[k], bt[i].c[k]); }
-    constexpr int NB = 16;
+#ifndef RT_SAH_BINS
+#define RT_SAH_BINS 16
+#endif
+    constexpr int NB = RT_SAH_BINS;
     double best = 1e300, best_plane = 0;
     int best_ax = -1;
     if (b - a > 2) {
@@ -1084,11 +1090,13 @@ void cull_fill(CullBuild &B, int a, int b, int depth, QuadRec &q, double lo[3], 
     if (depth > B.max_depth) B.max_depth = depth;
     std::vector<CullTri> &bt = *B.bt;
     int r[5], nr = 0; // child range boundaries
-    const int mid = cull_split(bt, a, b);
     r[nr++] = a;
-    if (mid - a >= 2) r[nr++] = cull_split(bt, a, mid);
-    r[nr++] = mid;
-    if (b - mid >= 2) r[nr++] = cull_split(bt, mid, b);
+    if (b - a >= 2) { // a list of one triangle gets a record with one child
+        const int mid = cull_split(bt, a, b);
+        if (mid - a >= 2) r[nr++] = cull_split(bt, a, mid);
+        r[nr++] = mid;
+        if (b - mid >= 2) r[nr++] = cull_split(bt, mid, b);
+    }
     r[nr] = b;
     for (int k = 0; k < 3; k++) { lo[k] = 1e300; hi[k] = -1e300; }
     double cl[4][3], ch[4][3];
