@@ -103,6 +103,12 @@ struct __attribute__((aligned(16))) QuadRec {
     unsigned item[4];
 };
 static_assert(sizeof(QuadRec) == 64, "QuadRec must be 64 bytes");
+// Boxes of a node's two children, quantised like a culling record's (single-precision base, step kept
+// as the upper 16 bits of a float, one byte per plane), so that the parent's step can skip a child
+// whose check_aabb is certain to fail.  Child 0 is the left child.
+struct __attribute__((aligned(16))) KidRec { float base[3]; unsigned short step16[3]; unsigned short pad; unsigned char q[2][3][2]; };
+static_assert(sizeof(KidRec) == 32, "KidRec is two granules");
+
 struct ListHdr { // per node, beside its list record: what the "near child finished" step needs
     unsigned right; // granule of the node's right child (0 = none), for the far-child step
     unsigned meta;  // bits of the (float) margin coefficient K of a long list, or LIST_SHORT | length
@@ -312,7 +318,8 @@ __device__ __forceinline__ void sincos_2pi(double x, double &sn, double &cs) {
 //   cull item   : IT_CULL | granule                          one inner record of a list's hierarchy
 //   tri item    : IT_TRI | chain << 28 | granule (28 bits)   one exact triangle test; with `chain` the next
 //                 triangle of the list follows directly, up to the one marked last (short lists)
-//   after item  : IT_AFTER | flag << 30 | far << 28 | node granule (28 bits)
+//   after item  : IT_AFTER | flag << 30 | far << 28 | node granule (28 bits); far: 0 none, 1 left, 2 right child,
+//                 3 = a far child whose box the ray is certain to miss (visited in name only)
 //                 the node's near child is done: own list, then the far child; `flag` is the
 //                 enclosing frame's "has a hit" so far.  Its record is the node's ListRec.
 constexpr unsigned IT_CULL = 1u << 29, IT_TRI = 2u << 29, IT_CHAIN = 1u << 28, IT_AFTER = 1u << 31, IDX29 = 0x1FFFFFFFu,
@@ -475,9 +482,12 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     rf[k] = S.ovf[(unsigned)lv * (unsigned)S.n_slots + gslot0 + (unsigned)slot];
                 }
             }
+            bool skipped = false; // the near child's visit was decided here (it is still a visit of the reference)
             if (run && !refill) { // ---- enter a node (kdtree.cpp:111-141)
                 const double2 *p = (const double2 *)(S.pool + (size_t)cur * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                const uint4 *kp = (const uint4 *)(S.pool + (size_t)(2u * S.g_list + (cur >> 1)) * 16); // the children's boxes
+                const uint4 k0 = kp[0], k1 = kp[1];
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
                 const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
                 const double mi[3] = {q0.x, q0.y, q1.x}, ma[3] = {q1.y, q2.x, q2.y};
@@ -528,8 +538,46 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     // kdtree.cpp:119-127 (left of the plane), 128-136 (right of it), 137-141 (on it: only
                     // the child the ray points into)
                     const bool nearL = hasL & (lt | (!gt & vneg)), nearR = hasR & !nearL & (gt | (!lt & vpos));
-                    const unsigned near = nearL ? node + 4 : nearR ? right : 0u;
-                    const unsigned farkind = (lt & hasR & vpos) ? 2u : (gt & hasL & vneg) ? 1u : 0u; // 1: left child, 2: right child
+                    unsigned near = nearL ? node + 4 : nearR ? right : 0u;
+                    unsigned farkind = (lt & hasR & vpos) ? 2u : (gt & hasL & vneg) ? 1u : 0u; // 1: left child, 2: right child
+                    // A child whose check_aabb is certain to fail is not visited, only counted: check_aabb
+                    // accepts nothing that misses the child's box grown by `pad` (see above), and the
+                    // quantised boxes contain the exact ones, so the single-precision slab test of the
+                    // culling records (same expression, same error bound, inflation `pad`) decides it.
+                    {
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        const float sf[3] = {(float)s[0], (float)s[1], (float)s[2]};
+                        const float ivf[3] = {cull_inv((float)inv[0]), cull_inv((float)inv[1]), cull_inv((float)inv[2])};
+                        const float mt = ((float)(pad * 1.000001) + S.fslack + 9.6e-7f * (fabsf(sf[0]) + fabsf(sf[1]) + fabsf(sf[2]))) * 1.000001f;
+                        const float kbase[3] = {__uint_as_float(k0.x), __uint_as_float(k0.y), __uint_as_float(k0.z)};
+                        const float kstep[3] = {__uint_as_float(k0.w << 16), __uint_as_float(k0.w & 0xFFFF0000u), __uint_as_float(k1.x << 16)};
+                        const unsigned kq[3] = {k1.y, k1.z, k1.w}; // 12 plane bytes: [child][axis][lower, upper]
+                        f2 ka[3], kb[3];
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            const float a1 = kstep[i] * ivf[i];
+                            ka[i] = (f2){a1, a1};
+                            kb[i] = (f2){(kbase[i] - (sf[i] + mt)) * ivf[i], (kbase[i] - (sf[i] - mt)) * ivf[i]};
+                        }
+                        bool met[2];
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            float ta[3], tb[3];
+#pragma unroll
+                            for (int i = 0; i < 3; i++) {
+                                const int bi = (k * 3 + i) * 2;
+                                const unsigned wd = kq[bi >> 2];
+                                const f2 qf = (bi & 2) ? (f2){(float)((wd >> 16) & 0xFFu), (float)(wd >> 24)} : (f2){(float)(wd & 0xFFu), (float)((wd >> 8) & 0xFFu)};
+                                const f2 t = __builtin_elementwise_fma(qf, ka[i], kb[i]);
+                                ta[i] = fminf(t.x, t.y);
+                                tb[i] = fmaxf(t.x, t.y);
+                            }
+                            const float tmin = fmaxf(fmaxf(ta[0], ta[1]), fmaxf(ta[2], 0.0f)), tmax = fminf(fminf(tb[0], tb[1]), tb[2]);
+                            met[k] = (tmin * 0.999999f <= tmax) | ((k1.x >> 16) != 0); // a record marked unusable culls nothing
+                        }
+                        if (near != 0 && !met[nearL ? 0 : 1]) { near = 0; skipped = true; } // its check() returns false at once
+                        if (farkind != 0 && !met[farkind == 1 ? 0 : 1]) farkind = 3;          // likewise, if it comes to that
+                    }
                     // the own list and the far child come after the near subtree; the frame's flag
                     // travels in the item and the near subtree starts with a clean one
                     const unsigned after = IT_AFTER | (((st >> 8) & 1u) << 30) | (farkind << 28) | node;
@@ -546,9 +594,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     if (sp - k >= 0) stk[(sp - k) & (LDS_STACK - 1)][slot] = rf[k];
                 slo = sp - (REFILL - 1) > 0 ? sp - (REFILL - 1) : 0;
             }
-            RT_SCOUNT(c_visits, nrun - (int)__popcll(__ballot(refill)));
+            RT_SCOUNT(c_visits, nrun - (int)__popcll(__ballot(refill)) + (int)__popcll(__ballot(skipped)));
         } else if (pick == K_CULL) {
-            bool boxes = false;
+            bool boxes = false, far_skipped = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
                 const unsigned g = (cur & IT_AFTER) ? S.g_list + (cur & IDX28) : (cur & IDX28);
                 const uint4 *p = (const uint4 *)(S.pool + (size_t)g * 16);
@@ -563,7 +611,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const unsigned node = cur & IDX28, farkind = (cur >> 28) & 3;
                     const bool near_hit = (st & ST_FLAG) != 0;         // what the near child's check() returned
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
-                    if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list
+                    if (farkind == 3) far_skipped = !near_hit; // the far child's check() fails at its box: a visit, nothing else
+                    else if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list
                     sL[slot] = node;                                     // the list now being scanned
                     if (meta & LIST_SHORT) { // up to SMALL_LIST triangles: a chain of tri steps in list order
                         boxes = false;
@@ -648,6 +697,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 }
             }
             RT_SCOUNT(c_culls, (unsigned)__popcll(__ballot(boxes)));
+            RT_SCOUNT(c_visits, (unsigned)__popcll(__ballot(far_skipped)));
         } else if (pick == K_TRI) {
             if (run) { // ---- one exact triangle test (kdtree.cpp:105)
                 const double2 *p = (const double2 *)(S.pool + (size_t)(cur & IDX28) * 16);
@@ -1140,6 +1190,48 @@ void cull_fill(CullBuild &B, int a, int b, int depth, QuadRec &q, double lo[3], 
     }
 }
 
+// quantises the boxes of the (up to two) children of a node; lo/hi[c] are exact bounds, has[c] says which exist
+void kid_fill(KidRec &kr, const double lo[2][3], const double hi[2][3], const bool has[2]) {
+    memset(&kr, 0, sizeof(kr));
+    if (!has[0] && !has[1]) return;
+    for (int k = 0; k < 3; k++) {
+        double l = 1e300, h = -1e300;
+        for (int c = 0; c < 2; c++)
+            if (has[c]) { l = std::min(l, lo[c][k]); h = std::max(h, hi[c][k]); }
+        const float base = f_down(l), top = f_up(h);
+        // the step keeps 16 bits: rounded up to the next such value, then raised until 255 steps reach the top
+        float st = f_up(((double)top - (double)base) / 255.0);
+        unsigned bits;
+        memcpy(&bits, &st, 4);
+        bits = (bits + 0xFFFFu) & 0xFFFF0000u;
+        memcpy(&st, &bits, 4);
+        if (!(st >= 0.0f) || !std::isfinite(st)) { st = 0.0f; bits = 0; }
+        for (int guard = 0; guard < 8 && st > 0.0f && (double)fmaf(255.0f, st, base) < h; guard++) {
+            bits += 0x10000u;
+            memcpy(&st, &bits, 4);
+        }
+        kr.base[k] = base;
+        kr.step16[k] = (unsigned short)(bits >> 16);
+        for (int c = 0; c < 2; c++) {
+            int b0 = 0, b1 = 255;
+            if (has[c] && st > 0.0f) {
+                b0 = (int)std::floor((lo[c][k] - (double)base) / (double)st);
+                b0 = std::max(0, std::min(255, b0));
+                while (b0 > 0 && (double)fmaf((float)b0, st, base) > lo[c][k]) b0--;
+                b1 = (int)std::ceil((hi[c][k] - (double)base) / (double)st);
+                b1 = std::max(0, std::min(255, b1));
+                while (b1 < 255 && (double)fmaf((float)b1, st, base) < hi[c][k]) b1++;
+                // a plane that cannot be placed outside the bound (non-finite or enormous coordinates) disables the axis
+                if ((double)fmaf((float)b0, st, base) > lo[c][k] || (double)fmaf((float)b1, st, base) < hi[c][k]) { kr.pad = 1; }
+            } else if (has[c]) { // flat union box: every plane is `base`; usable only if that is the exact coordinate
+                b0 = b1 = 0;
+                if ((double)base > lo[c][k] || (double)base < hi[c][k]) kr.pad = 1;
+            }
+            kr.q[c][k][0] = (unsigned char)b0; kr.q[c][k][1] = (unsigned char)b1;
+        }
+    }
+}
+
 // fills the list record of a list longer than SMALL_LIST and permutes order[first..first+count)
 void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<QuadRec> &cull, unsigned cull_base,
                 unsigned tri_base, QuadRec &li, ListHdr &hdr, int &max_depth) {
@@ -1331,9 +1423,9 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (dev < 0 || dev >= ndev) return fail(RT_E_INVALID, "device %d not in [0,%d)", dev, ndev);
     HIP_TRY(hipSetDevice(dev));
 
-    // pool layout in 16-byte granules: nodes (4 each), their list records (4 each), triangles (5), cull records (4);
-    // how many cull records the hierarchies take is only known once they are built
-    const size_t g_list = 4 * (size_t)D->n_nodes, g_tri = g_list + 4 * (size_t)D->n_nodes,
+    // pool layout in 16-byte granules: nodes (4 each), their list records (4 each), their child-box records (2 each),
+    // triangles (5), cull records (4); how many cull records the hierarchies take is only known once they are built
+    const size_t g_list = 4 * (size_t)D->n_nodes, g_kid = 2 * g_list, g_tri = g_kid + 2 * (size_t)D->n_nodes,
                  g_cull = (g_tri + 5 * (size_t)D->n_tris + 3) & ~(size_t)3;
     if (g_cull + 4 > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
     std::vector<char> pool(g_cull * 16, 0);
@@ -1358,6 +1450,17 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
             li.item[0] = IT_TRI | IT_CHAIN | ((unsigned)g_tri + 5u * (unsigned)first);
         }
         hdr.right = n.right;
+        {
+            KidRec kr;
+            double klo[2][3] = {{0, 0, 0}, {0, 0, 0}}, khi[2][3] = {{0, 0, 0}, {0, 0, 0}};
+            const int kid[2] = {D->node_left[i] >= 0 ? i + 1 : -1, D->node_right[i] > 0 ? D->node_right[i] : -1};
+            const bool has[2] = {kid[0] >= 0, kid[1] >= 0};
+            for (int c = 0; c < 2; c++)
+                if (has[c])
+                    for (int k = 0; k < 3; k++) { klo[c][k] = D->node_box[6 * (size_t)kid[c] + k]; khi[c][k] = D->node_box[6 * (size_t)kid[c] + 3 + k]; }
+            kid_fill(kr, klo, khi, has);
+            memcpy(&pool[(g_kid + 2 * (size_t)i) * 16], &kr, 32);
+        }
         memcpy(&pool[(size_t)i * 64], &n, 64);
         memcpy(&pool[(g_list + 4 * (size_t)i) * 16], &li, 64);
     }
