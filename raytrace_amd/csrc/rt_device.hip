@@ -75,7 +75,8 @@ constexpr int N_STATS = 9;
 #ifndef RT_SMALL_LIST
 #define RT_SMALL_LIST 1
 #endif
-constexpr int SMALL_LIST = RT_SMALL_LIST; // own lists up to this length are tested directly, longer ones get a hierarchy
+constexpr int SMALL_LIST = RT_SMALL_LIST;
+constexpr int SPH_HIER_MIN = 16; // scenes with at least this many spheres get a hierarchy over them // own lists up to this length are tested directly, longer ones get a hierarchy
 
 // Every traversal record lives in ONE pool addressed in 16-byte granules, and a work item carries
 // the granule of its record:
@@ -144,6 +145,10 @@ struct DevScene {
     double reach;  // its summed half extents + the scene's longest triangle edge
     double absn;   // |centre|_1 + summed half extents
     unsigned g_list; // granule of node 0's list record
+    unsigned g_sph;  // granule of sphere 0's copy in the pool (two granules per sphere); tri items from here on are spheres
+    unsigned sph_root; // item of the sphere hierarchy's root record, 0 = spheres are scanned in the shade step
+    float sph_k, sph_c; // inflation of the sphere boxes: sph_k * (bound on |centre - origin|)^2 + sph_c
+    double sph_cen[3], sph_h; // centre and summed half extents of the box around all spheres
     const ListHdr *lhdr; // per node
     float fslack;    // part of the single-precision slab test's safety margin that depends on the scene only
     double padc;   // constant part of the node-box padding: 2.5e-5 + 4e-12 * (largest sum of |box coordinates| of a node)
@@ -341,8 +346,9 @@ enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, S
 //   LS_V    ray direction;  LS_BT best distance so far
 //   LS_HA   low: best triangle (TriShade index)
 //   LS_HB   best triangle's list rank (low) and list (high)
+//   LS_ST   nearest sphere's distance, LS_SI its index (-1 none, -2: not searched through the hierarchy)
 enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13, LS_OUT = 14, LS_V = 15, LS_BT = 18, LS_HA = 19,
-       LS_HB = 20, LS_PEND = 21 };
+       LS_HB = 20, LS_ST = 21, LS_SI = 22, LS_PEND = 23 };
 constexpr int PEND_WORDS = 10;
 constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
 // per-slot flags word in LDS: stack depth (bits 0-7), the frame's "has a hit" flag (8), the kind
@@ -372,7 +378,8 @@ constexpr int ST_KIND = 9, ST_LO = 12;
 // and report the nearest triangle / sphere (raytrace.cpp:46-47).
 __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30f), 1e30f); }
 
-template <bool TRACE>
+// SPH = true: the scene has a sphere hierarchy (a second instance, so that scenes without one do not pay for it).
+template <bool TRACE, bool SPH>
 __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCamera cam, rt_params P, const DevTile *tiles, int n_tiles,
                                                              unsigned n_work, unsigned *counter, double *rgb, int *prim,
                                                              const double *rays, int *tri_id, double *tri_t, int *sph_id,
@@ -623,6 +630,15 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                         sM[slot] = mg;
                     }
                 }
+                if (SPH && !(cur & IT_AFTER) && (cur & IT_CHAIN)) { // root of the sphere hierarchy: the kd-tree is done
+                    // Sphere::intersect (sphere.h:13-21) accepts a unit-length ray only within
+                    // r + (5.1e-13 |op|^2 + 3e-16 r^2) / r of the centre (rounding of det and of |d|^2 - 1,
+                    // which the ray's start bounds by 1e-12); |op| <= |o - C|_1 + H for every sphere
+                    const double gs = fabs(a.x - S.sph_cen[0]) + fabs(a.y - S.sph_cen[1]) + fabs(b.x - S.sph_cen[2]) + S.sph_h;
+                    const float gsf = (float)gs * 1.000001f;
+                    mg = S.sph_k * gsf * gsf + S.sph_c;
+                    sM[slot] = mg;
+                }
                 if (boxes) {
                     // Slab test of the four inflated boxes in single precision, two planes per packed
                     // instruction: the ray parameter of the plane base + q * step is evaluated as
@@ -699,6 +715,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             RT_SCOUNT(c_culls, (unsigned)__popcll(__ballot(boxes)));
             RT_SCOUNT(c_visits, (unsigned)__popcll(__ballot(far_skipped)));
         } else if (pick == K_TRI) {
+            bool is_sph = false;
             if (run) { // ---- one exact triangle test (kdtree.cpp:105)
                 const double2 *p = (const double2 *)(S.pool + (size_t)(cur & IDX28) * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
@@ -708,7 +725,29 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const unsigned cur_list = sL[slot];
                 const double2 a = sA[slot], b = sB[slot];
                 const d3 o = mk(a.x, a.y, b.x);
-                const double t = tri_hit(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d);
+                is_sph = SPH && (cur & IDX28) >= S.g_sph;
+                if (is_sph) { // ---- one sphere of the sphere hierarchy (sphere.h:13-21, sphere.cpp:7)
+                    const int i = (int)(((cur & IDX28) - S.g_sph) >> 1);
+                    const d3 op = mk(q0.x, q0.y, q1.x) - o; // the pool's copy of the sphere: centre, radius
+                    const double rad = q1.y;
+                    const double bb = dot(op, d);
+                    double det = bb * bb - dot(op, op) + rad * rad;
+                    double t;
+                    if (det < 0) t = 1e20;
+                    else {
+                        det = sqrt(det);
+                        t = bb - det;
+                        if (!(t > EPS)) { t = bb + det; if (!(t > EPS)) t = 1e20; }
+                    }
+                    const double ts = ls[LS_ST * lss];
+                    // the reference scans from the last sphere down with strict <: of equal distances the higher index wins
+                    if (t < ts || (t == ts && t < 1e20 && i > (int)__double_as_longlong(ls[LS_SI * lss]))) {
+                        ls[LS_ST * lss] = t;
+                        ls[LS_SI * lss] = __longlong_as_double((long long)i);
+                    }
+                    want_pop = true;
+                }
+                const double t = is_sph ? 0.0 : tri_hit(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d);
                 if (t > EPS) {
                     const int rk = (int)(w9 >> 32);
                     // strict < keeps the earlier of two equal distances; inside one list "earlier"
@@ -725,7 +764,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     }
                     if (t < 1e10) st |= ST_FLAG;
                 }
-                if ((cur & IT_CHAIN) && !((unsigned)w9 & TRI_LAST)) next = cur + 5u; // the list's next triangle
+                if (is_sph) {}
+                else if ((cur & IT_CHAIN) && !((unsigned)w9 & TRI_LAST)) next = cur + 5u; // the list's next triangle
                 else want_pop = true;
 #ifdef RT_PROFILE
                 p_tri[0] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) != 0));          // tests of short lists
@@ -734,7 +774,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 p_tri[3] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) == 0 && t > EPS)); // ... that hit
 #endif
             }
-            RT_SCOUNT(c_done, nrun);
+            RT_SCOUNT(c_done, nrun - (int)__popcll(__ballot(is_sph)));
         } else {
             bool ev_ray = false, ev_shade = false;
             if (run) { // ---- traversal finished (or nothing started yet)
@@ -757,7 +797,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const int tpos = (int)((const unsigned *)&ls[LS_HA * lss])[0];
                     double ts;
                     int ids;
-                    trace_spheres(S, o, d, ts, ids);
+                    const long long wsi = SPH ? __double_as_longlong(ls[LS_SI * lss]) : -2ll;
+                    if (wsi != -2ll) { ts = ls[LS_ST * lss]; ids = (int)wsi; } // found through the hierarchy
+                    else trace_spheres(S, o, d, ts, ids);
                     const bool fo = to < 1e10, fs = ts < 1e10;
                     if (TRACE) {
                         if (fo && !(ts < to)) ev_shade = true;
@@ -945,6 +987,12 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     sG[slot] = gf;
                     st = 0;
                     sp = 0; slo = 0;
+                    if (SPH) { // many spheres: their hierarchy is searched after the kd-tree, from the bottom of the stack
+                        const bool unit = fabs(dot(rd, rd) - 1.0) <= 1e-12; // what the boxes' inflation assumes
+                        ls[LS_ST * lss] = 1e20;
+                        ls[LS_SI * lss] = __longlong_as_double(unit ? -1ll : -2ll);
+                        if (unit) { stk[0][slot] = S.sph_root; sp = 1; }
+                    }
                     ev_ray = true;
                     // next stays 0: the root node
                 } else want_pop = true; // sp is 0: the slot stays idle (done, or out of work)
@@ -1066,6 +1114,8 @@ struct CullBuild {
     unsigned cull_base, tri_base; // granules
     int first;                    // list position of the range's first triangle
     int max_depth;
+    unsigned leaf_stride = 5;     // granules per leaf record
+    bool by_src = false;          // leaves are addressed by their source index (spheres) instead of their list position
 };
 
 // Splits the range [a, b) (b - a >= 2) in two and returns the split point: the plane between 16
@@ -1155,7 +1205,7 @@ void cull_fill(CullBuild &B, int a, int b, int depth, QuadRec &q, double lo[3], 
         const int ca = r[c], cb = r[c + 1];
         if (cb - ca == 1) {
             for (int k = 0; k < 3; k++) { cl[c][k] = bt[ca].lo[k]; ch[c][k] = bt[ca].hi[k]; }
-            q.item[c] = IT_TRI | (B.tri_base + 5u * (unsigned)(B.first + ca));
+            q.item[c] = IT_TRI | (B.tri_base + B.leaf_stride * (unsigned)(B.by_src ? bt[ca].src : B.first + ca));
         } else {
             const size_t me = B.out->size();
             B.out->emplace_back();
@@ -1378,7 +1428,8 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     const DevCamera dc = make_camera(cam);
     const int grid = (int)std::min<long long>(s->grid, (blocks + RAYS_PER_LANE - 1) / RAYS_PER_LANE);
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(k_main<false>, dim3(grid), dim3(WAVE), 0, stream, s->d, dc, *p, (const DevTile *)s->d_tiles, n_tiles,
+    const auto kern = s->d.sph_root ? k_main<false, true> : k_main<false, false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, dc, *p, (const DevTile *)s->d_tiles, n_tiles,
                        (unsigned)(blocks * 64), s->d_counter, d_rgb, d_prim, (const double *)nullptr, (int *)nullptr,
                        (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats);
     HIP_TRY(hipGetLastError());
@@ -1426,7 +1477,8 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     // pool layout in 16-byte granules: nodes (4 each), their list records (4 each), their child-box records (2 each),
     // triangles (5), cull records (4); how many cull records the hierarchies take is only known once they are built
     const size_t g_list = 4 * (size_t)D->n_nodes, g_kid = 2 * g_list, g_tri = g_kid + 2 * (size_t)D->n_nodes,
-                 g_cull = (g_tri + 5 * (size_t)D->n_tris + 3) & ~(size_t)3;
+                 g_sph = g_tri + 5 * (size_t)D->n_tris, // copies of the spheres (2 granules each) for the sphere hierarchy's leaves
+                 g_cull = (g_sph + 2 * (size_t)D->n_spheres + 6) & ~(size_t)3;
     if (g_cull + 4 > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
     std::vector<char> pool(g_cull * 16, 0);
     std::vector<QuadRec> cull;
@@ -1463,6 +1515,41 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         }
         memcpy(&pool[(size_t)i * 64], &n, 64);
         memcpy(&pool[(g_list + 4 * (size_t)i) * 16], &li, 64);
+    }
+    // Scenes with many spheres: the same kind of hierarchy over the spheres' boxes, searched after the kd-tree
+    // (the reference scans all of them for every ray, sphere.cpp:3-14).  Its root is one more cull record.
+    unsigned sph_root = 0;
+    float sph_k = 0.0f, sph_c = 0.0f;
+    double sph_cen[3] = {0, 0, 0}, sph_h = 0;
+    if (D->n_spheres >= SPH_HIER_MIN) {
+        std::vector<CullTri> bt((size_t)D->n_spheres);
+        double rmin = 1e300, rmax = 0, cabs = 0;
+        for (int i = 0; i < D->n_spheres; i++) {
+            const double r = D->sph_rad[i];
+            rmin = std::min(rmin, r); rmax = std::max(rmax, r);
+            for (int k = 0; k < 3; k++) {
+                bt[i].c[k] = D->sph_pos[3 * i + k];
+                bt[i].lo[k] = bt[i].c[k] - fabs(r); bt[i].hi[k] = bt[i].c[k] + fabs(r);
+                cabs = std::max(cabs, std::max(fabs(bt[i].lo[k]), fabs(bt[i].hi[k])));
+            }
+            bt[i].src = i;
+            memcpy(&pool[(g_sph + 2 * (size_t)i) * 16], D->sph_pos + 3 * i, 24);
+            memcpy(&pool[(g_sph + 2 * (size_t)i) * 16 + 24], &r, 8);
+        }
+        CullBuild B = {&cull, &bt, (unsigned)g_cull, (unsigned)g_sph, 0, 0};
+        B.leaf_stride = 2; B.by_src = true;
+        QuadRec root;
+        double lo[3], hi[3];
+        cull_fill(B, 0, D->n_spheres, 1, root, lo, hi);
+        cull_depth = std::max(cull_depth, B.max_depth);
+        sph_root = IT_CULL | IT_CHAIN | (unsigned)(g_cull + 4 * cull.size());
+        cull.push_back(root);
+        for (int k = 0; k < 3; k++) { sph_cen[k] = 0.5 * (lo[k] + hi[k]); sph_h += 0.5 * (hi[k] - lo[k]) * 1.000001 + 1e-300; }
+        // inflation = sph_k * G^2 + sph_c: the acceptance bound of the exact test (see the cull step) with a factor
+        // of two to spare, plus the single-precision slab test's slack for the spheres' own coordinates
+        sph_k = f_up(1.1e-12 / rmin);
+        if (!(rmin > 0) || !std::isfinite(sph_k)) sph_k = INFINITY;
+        sph_c = f_up(1e-15 * rmax + 16.0 * 5.97e-8 * cabs);
     }
     const size_t n_cull = cull.size();
     const size_t g_end = g_cull + 4 * n_cull + 4;
@@ -1529,12 +1616,12 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     hipDeviceProp_t pr;
     int per_cu = 0;
     if (hipGetDeviceProperties(&pr, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_main<false>, WAVE, 0) != hipSuccess || per_cu < 1)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_main<false, true>), WAVE, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
     s->grid = pr.multiProcessorCount * per_cu;
     const int n_slots = s->grid * SLOTS;
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
-    const int need_depth = D->tree_depth + 3 * cull_depth + 4;
+    const int need_depth = D->tree_depth + 3 * cull_depth + 4 + (sph_root ? 1 : 0);
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK + 1 : 0; // levels that can move to HBM
     if ((long long)ovf_depth * n_slots >= (1ll << 31)) {
         rt_free_scene(s);
@@ -1577,6 +1664,11 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     }
     s->d.padc = 2.5e-5 + 4e-12 * boxsum;
     s->d.g_list = (unsigned)g_list;
+    s->d.g_sph = (unsigned)g_sph;
+    s->d.sph_root = sph_root;
+    s->d.sph_k = sph_k; s->d.sph_c = sph_c;
+    for (int k = 0; k < 3; k++) s->d.sph_cen[k] = sph_cen[k];
+    s->d.sph_h = sph_h;
     s->d.lhdr = (const ListHdr *)s->lhdr;
     s->d.fslack = f_up(16.0 * 5.97e-8 * (s->d.absn + s->d.reach)); // see the cull step
     s->d.n_sph = D->n_spheres;
@@ -1692,7 +1784,8 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
         const int grid = (int)std::min<long long>(s->grid, want); // stay within the slot count the state arrays were sized for
         rt_params none = {1, 0, 0, 0, 1, 0, 0};
         DevCamera nocam = {};
-        hipLaunchKernelGGL(k_main<true>, dim3(grid), dim3(WAVE), 0, nullptr, s->d, nocam, none, (const DevTile *)nullptr, 0,
+        const auto kern = s->d.sph_root ? k_main<true, true> : k_main<true, false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, nullptr, s->d, nocam, none, (const DevTile *)nullptr, 0,
                            (unsigned)n, s->d_counter, (double *)nullptr, (int *)nullptr, (const double *)d_rays, d_ti, d_tt, d_si,
                            d_st, s->d_stats);
         e = hipGetLastError();

@@ -271,6 +271,51 @@ def test_edge_scenes(ra, po):
     dev.close()
 
 
+def test_sphere_hierarchy_matches_brute_force_scan(ra, po):
+    """Scenes with 16 or more spheres search them through a hierarchy after the kd-tree; the reference
+    scans all of them (sphere.cpp:3-14).  Same ids, distances and work counters as the oracle for random
+    rays, axis-parallel rays, rays that start inside spheres, coincident and touching spheres, and
+    directions that are not unit length (those fall back to the scan); full paths agree too."""
+    from raytrace_amd import scenes
+    sc = scenes.random_spheres(400, 24, 32, seed=7)
+    sph = sc["spheres"]
+    sph += [scenes._sphere(3, (50, 50, 40), (0, 0, 0), (.5, .5, .5), 0)] * 3            # coincident: the last index wins
+    sph += [scenes._sphere(2, (60, 50, 40), (0, 0, 0), (.5, .5, .5), 0), scenes._sphere(2, (64, 50, 40), (0, 0, 0), (.5, .5, .5), 0)]
+    sph += [scenes._sphere(1e4, (50, -1e4 - 120, 0), (0, 0, 0), (.7, .7, .7), 0)]       # a huge one under everything
+    tri = np.array([[-200, -200, -150, 300, -200, -150, 50, 300, -150.0]])
+    for meshes in ([], [scenes._mesh(tri, (.5, .5, .5))]):
+        scn = {"meshes": meshes, "spheres": sph}
+        hs = ra.HostScene(scn)
+        dev = ra.DeviceScene(hs, 0)
+        orc = po.OracleScene(scn)
+        rs = np.random.RandomState(5)
+        o = rs.uniform(-120, 220, (6000, 3))
+        d = rs.normal(size=(6000, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([o, d], 1)
+        rays[:200, 3:] = np.eye(3)[rs.randint(0, 3, 200)] * rs.choice([-1.0, 1.0], (200, 1))  # axis-parallel
+        rays[200:300, :3] = np.array([s_["pos"] for s_ in sph[:100]])                               # from sphere centres
+        rays[300:330] = [62, 50, 90, 0, 0, -1.0]                                                    # through the touching point
+        rays[330:360] = [50, 50, 90, 0, 0, -1.0]                                                    # at the coincident spheres
+        rays[360:460, 3:] *= rs.uniform(0.3, 3.0, (100, 1))                                         # not unit length
+        a = dev.trace_rays(rays)
+        b = orc.trace(rays)
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+        assert {k: a[4][k] for k in b[4]} == b[4]
+        assert (a[2] >= 0).sum() > 1000
+        assert a[2][330] == len(sph) - 4  # the last of the three coincident spheres
+        cam = ra.capi.make_camera((50, 50, 300), (0, 0, -1), 24, 32)
+        ocam = po.make_camera((50, 50, 300), (0, 0, -1), 24, 32)
+        kw = dict(samps=1, rr_depth=4, rr_mode=0, split_depth=2, hard_depth=8, jitter=1, seed=3)
+        rgb, pid, st = dev.render_tile(cam, ra.capi.make_params(**kw), 0, 0, 24, 32)
+        orgb, opid, ost = orc.render_tile(ocam, po.make_params(**kw), 0, 0, 24, 32)
+        assert np.array_equal(pid, opid)
+        assert (np.abs(rgb - orgb).max(axis=-1) <= 1e-9).mean() >= 0.999
+        assert {k: st[k] for k in ost} == ost
+        dev.close()
+
+
 def test_invalid_arguments_are_rejected(ra, world):
     w = world["tiny"]
     cam = _cam(ra, w["scene"], 16, 16)
