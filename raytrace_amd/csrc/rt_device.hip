@@ -383,7 +383,8 @@ template <bool TRACE, bool SPH>
 __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCamera cam, rt_params P, const DevTile *tiles, int n_tiles,
                                                              unsigned n_work, unsigned *counter, double *rgb, int *prim,
                                                              const double *rays, int *tri_id, double *tri_t, int *sph_id,
-                                                             double *sph_t, unsigned long long *gstats) {
+                                                             double *sph_t, unsigned long long *gstats, double *subbuf,
+                                                             unsigned *subcnt) {
     __shared__ double2 sA[SLOTS]; // origin x, y
     __shared__ double2 sB[SLOTS]; // origin z, 1/direction x
     __shared__ double2 sC[SLOTS]; // 1/direction y, z
@@ -413,6 +414,11 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         sQ[qindex(K_SHADE, lane + r * WAVE)] = make_uint2((unsigned)(lane + r * WAVE), 0u);
     }
     int q0 = 0, q1 = 0, q2 = 0, q3 = SLOTS; // entries on the four stacks
+    // pieces of work taken from the counter and not handed to a slot yet: first piece, count (in LDS because only
+    // the lanes of a shade step see an update)
+    // (volatile: one lane writes what the others read; the compiler must not keep a lane's old value)
+    __shared__ volatile unsigned sStash[2];
+    if (lane == 0) { sStash[0] = 0u; sStash[1] = 0u; }
     // work counters: wavefront-uniform 32-bit sums of lane counts in scalar registers, flushed to
     // the 64-bit totals in HBM long before they can overflow; only the own-list lengths need a
     // per-lane sum
@@ -894,16 +900,30 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                             const double is = 1.0 / samps;
                             d3 rsum = mk(ls[LS_RSUM * lss] + ls[LS_ACC * lss] * is, ls[(LS_RSUM + 1) * lss] + ls[(LS_ACC + 1) * lss] * is,
                                          ls[(LS_RSUM + 2) * lss] + ls[(LS_ACC + 2) * lss] * is);
-                            if (++smp == samps) {
+                            if (++smp == samps) { // the sub-pixel is complete: its share of the pixel (raytrace.cpp:205)
                                 smp = 0;
-                                const d3 col = mk(ls[LS_COL * lss] + clamp01(rsum.x) * .25, ls[(LS_COL + 1) * lss] + clamp01(rsum.y) * .25,
-                                                  ls[(LS_COL + 2) * lss] + clamp01(rsum.z) * .25);
+                                // The four sub-pixels of a pixel are separate pieces of work of ONE wavefront (see the
+                                // hand-out below); whichever finishes last adds the shares in the reference's order, so
+                                // the sum does not depend on who that is.  All of it stays inside one CU: the shares go
+                                // to L2 and are read back from there (device-scope accesses, no cache maintenance).
+                                double *sc = subbuf + ((size_t)outk * 4 + (size_t)sub) * 3;
+                                __hip_atomic_store(sc, clamp01(rsum.x) * .25, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(sc + 1, clamp01(rsum.y) * .25, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(sc + 2, clamp01(rsum.z) * .25, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 rsum = mk(0, 0, 0);
-                                if (++sub == 4) {
-                                    sub = 0;
-                                    rgb[3 * (size_t)outk] = col.x; rgb[3 * (size_t)outk + 1] = col.y; rgb[3 * (size_t)outk + 2] = col.z;
-                                    need_work = true;
-                                } else { ls[LS_COL * lss] = col.x; ls[(LS_COL + 1) * lss] = col.y; ls[(LS_COL + 2) * lss] = col.z; }
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the stores have left the CU
+                                if (__hip_atomic_fetch_add(subcnt + outk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3u) {
+                                    const double *pc = subbuf + (size_t)outk * 12;
+#pragma unroll
+                                    for (int k = 0; k < 3; k++) {
+                                        const double s0 = __hip_atomic_load(pc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                                     s1 = __hip_atomic_load(pc + 3 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                                     s2 = __hip_atomic_load(pc + 6 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                                     s3 = __hip_atomic_load(pc + 9 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        rgb[3 * (size_t)outk + k] = ((s0 + s1) + s2) + s3;
+                                    }
+                                }
+                                need_work = true;
                             }
                             ls[LS_RSUM * lss] = rsum.x; ls[(LS_RSUM + 1) * lss] = rsum.y; ls[(LS_RSUM + 2) * lss] = rsum.z;
                             need_primary = !need_work;
@@ -912,19 +932,29 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 } else need_work = true; // first step of the slot: nothing traced yet
 
                 // ---- slots without work take the next pixel (or ray) from the shared counter
+                // (render: in whole pixels, i.e. multiples of four pieces, so that a pixel's sub-pixels stay in this
+                // wavefront; what is left over waits in [stash_base, stash_base + stash_n) for the next slots)
                 for (;;) {
                     const unsigned long long want = __ballot(need_work);
                     if (want == 0) break;
+                    const unsigned k = (unsigned)__popcll(want);
+                    const unsigned was_base = sStash[0], was_n = sStash[1];
+                    const unsigned take = k <= was_n ? 0u : TRACE ? k : ((k - was_n + 3u) & ~3u);
                     unsigned base = 0;
                     const int leader = __ffsll((long long)want) - 1;
-                    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(want));
+                    if (take != 0 && lane == leader) base = atomicAdd(counter, take);
                     base = __shfl(base, leader, 64);
+                    if (lane == leader) {
+                        if (k >= was_n) { sStash[0] = base + (k - was_n); sStash[1] = take - (k - was_n); }
+                        else { sStash[0] = was_base + k; sStash[1] = was_n - k; }
+                    }
                     if (need_work) {
-                        const unsigned w = base + (unsigned)__popcll(want & lane_lt);
+                        const unsigned r = (unsigned)__popcll(want & lane_lt);
+                        const unsigned w = r < was_n ? was_base + r : base + (r - was_n);
                         if (w >= n_work) { need_work = false; done = true; }
                         else if (TRACE) { outk = w; need_work = false; go_on = true; ro = ld3(rays + 6 * (size_t)w); rd = ld3(rays + 6 * (size_t)w + 3); }
                         else {
-                            const unsigned blk = w >> 6, li = w & 63;
+                            const unsigned blk = w >> 8, li = (w >> 2) & 63; // a block of 8 x 8 pixels is 256 pieces: pixel, sub-pixel
                             int lo = 0, hi = n_tiles - 1; // last tile whose first block is <= blk
                             while (lo < hi) {
                                 const int mid = (lo + hi + 1) >> 1;
@@ -936,8 +966,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                             if (lrow < T.rows && lcol < T.cols) { // ragged edge blocks have unused lanes
                                 pxy = ((unsigned)(T.x0 + lrow) << 16) | (unsigned)(T.y0 + lcol);
                                 outk = (unsigned)(T.out_off + (long long)lrow * T.cols + lcol);
-                                sub = 0; smp = 0;
-                                ls[LS_COL * lss] = 0; ls[(LS_COL + 1) * lss] = 0; ls[(LS_COL + 2) * lss] = 0;
+                                sub = (int)(w & 3); smp = 0;
                                 ls[LS_RSUM * lss] = 0; ls[(LS_RSUM + 1) * lss] = 0; ls[(LS_RSUM + 2) * lss] = 0;
                                 need_work = false;
                                 need_primary = true;
@@ -1090,6 +1119,9 @@ struct rt_scene {
     DevTile *d_tiles = nullptr;
     int tiles_cap = 0;
     std::vector<DevTile> h_tiles;
+    double *d_sub = nullptr;     // shares of the sub-pixels of the frame being rendered [pixel][4][3]
+    unsigned *d_subcnt = nullptr; // finished sub-pixels per pixel
+    size_t sub_cap = 0;          // pixels both hold
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     hipStream_t last_stream = nullptr;
@@ -1409,7 +1441,7 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         d.blk_cols = (t.cols + 7) / 8;
         off += (long long)t.rows * t.cols;
         blocks += (long long)((t.rows + 7) / 8) * d.blk_cols;
-        if (blocks > 0x1FFFFFFLL) return fail(RT_E_LIMIT, "too many pixel blocks in one launch");
+        if (blocks > 0xFFFFFELL) return fail(RT_E_LIMIT, "too many pixel blocks in one launch");
     }
     HIP_TRY(hipSetDevice(s->dev));
     if (n_tiles > s->tiles_cap) {
@@ -1424,14 +1456,23 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         s->h_tiles = ht; // the copy below reads s->h_tiles, which stays alive until the next call
         HIP_TRY(hipMemcpyAsync(s->d_tiles, s->h_tiles.data(), sizeof(DevTile) * ht.size(), hipMemcpyHostToDevice, stream));
     }
+    if ((size_t)off > s->sub_cap) {
+        if (s->d_sub) HIP_TRY(hipFree(s->d_sub));
+        if (s->d_subcnt) HIP_TRY(hipFree(s->d_subcnt));
+        s->d_sub = nullptr; s->d_subcnt = nullptr; s->sub_cap = 0;
+        HIP_TRY(hipMalloc((void **)&s->d_sub, (size_t)off * 12 * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&s->d_subcnt, (size_t)off * sizeof(unsigned)));
+        s->sub_cap = (size_t)off;
+    }
+    HIP_TRY(hipMemsetAsync(s->d_subcnt, 0, (size_t)off * sizeof(unsigned), stream));
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, 16, stream));
     const DevCamera dc = make_camera(cam);
-    const int grid = (int)std::min<long long>(s->grid, (blocks + RAYS_PER_LANE - 1) / RAYS_PER_LANE);
+    const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + SLOTS - 1) / SLOTS);
     HIP_TRY(hipEventRecord(s->ev0, stream));
     const auto kern = s->d.sph_root ? k_main<false, true> : k_main<false, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, dc, *p, (const DevTile *)s->d_tiles, n_tiles,
-                       (unsigned)(blocks * 64), s->d_counter, d_rgb, d_prim, (const double *)nullptr, (int *)nullptr,
-                       (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats);
+                       (unsigned)(blocks * 256), s->d_counter, d_rgb, d_prim, (const double *)nullptr, (int *)nullptr,
+                       (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats, s->d_sub, s->d_subcnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     s->timed = true;
@@ -1681,7 +1722,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_stats, s->d_tiles};
+    void *ptrs[] = {s->pool, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -1787,7 +1828,7 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
         const auto kern = s->d.sph_root ? k_main<true, true> : k_main<true, false>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, nullptr, s->d, nocam, none, (const DevTile *)nullptr, 0,
                            (unsigned)n, s->d_counter, (double *)nullptr, (int *)nullptr, (const double *)d_rays, d_ti, d_tt, d_si,
-                           d_st, s->d_stats);
+                           d_st, s->d_stats, (double *)nullptr, (unsigned *)nullptr);
         e = hipGetLastError();
         s->last_stream = nullptr;
     }
