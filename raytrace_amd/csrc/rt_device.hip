@@ -112,7 +112,8 @@ static_assert(sizeof(KidRec) == 32, "KidRec is two granules");
 
 struct ListHdr { // per node, beside its list record: what the "near child finished" step needs
     unsigned right; // granule of the node's right child (0 = none), for the far-child step
-    unsigned meta;  // bits of the (float) margin coefficient K of a long list, or LIST_SHORT | length
+    unsigned meta;  // LIST_SHORT | length, or a long list's margin coefficients: bits 8-30 the upper bits of the (float)
+                    // working coefficient K, bits 0-7 an exponent r; K * 2^r bounds the coefficient of every triangle
 };
 constexpr unsigned LIST_SHORT = 0x80000000u;
 
@@ -632,7 +633,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                         if ((meta & 0xFF) == 0) want_pop = true;
                         else next = it.x;
                     } else { // inflation of this list's boxes, see ray_margin_factor(); a larger one only culls less
-                        mg = __uint_as_float(meta) * sG[slot];
+                        const float gfac = sG[slot]; // negative for a ray from far outside the scene: the larger coefficient
+                        // (the exponent in the low mantissa bits only makes the coefficient a little larger)
+                        mg = ldexpf(__uint_as_float(meta), gfac < 0.0f ? (int)(meta & 0xFFu) : 0) * fabsf(gfac);
                         sM[slot] = mg;
                     }
                 }
@@ -1013,7 +1016,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     ls[LS_HA * lss] = __longlong_as_double(-1ll);                   // no triangle
                     ls[LS_HB * lss] = __longlong_as_double((long long)0xFFFFFFFE00000000ull); // a list that is never current
                     sL[slot] = 0xFFFFFFFFu;
-                    sG[slot] = gf;
+                    // negative: beyond the factor (4 * reach + 1 at upload) that the lists' working coefficients cover
+                    sG[slot] = gf <= (float)(3.9 * S.reach) ? gf : -gf;
                     st = 0;
                     sp = 0; slo = 0;
                     if (SPH) { // many spheres: their hierarchy is searched after the kd-tree, from the bottom of the stack
@@ -1316,10 +1320,12 @@ void kid_fill(KidRec &kr, const double lo[2][3], const double hi[2][3], const bo
 
 // fills the list record of a list longer than SMALL_LIST and permutes order[first..first+count)
 void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<QuadRec> &cull, unsigned cull_base,
-                unsigned tri_base, QuadRec &li, ListHdr &hdr, int &max_depth) {
+                unsigned tri_base, QuadRec &li, ListHdr &hdr, int &max_depth, double g0) {
     std::vector<CullTri> bt((size_t)count);
+    std::vector<double> kt((size_t)count); // margin coefficient 2 * (1e-9 L^2 + 1e-10) of each triangle, L its longest edge
     double lmax2 = 0;
     for (int j = 0; j < count; j++) {
+        double tl2 = 0;
         const double *v = D->tri_verts + 9 * (size_t)D->list_tri[first + j];
         CullTri &t = bt[j];
         t.src = first + j;
@@ -1332,16 +1338,41 @@ void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &
             const double *p = v + 3 * e, *q = v + 3 * ((e + 1) % 3);
             const double l2 = (p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]);
             lmax2 = std::max(lmax2, l2);
+            tl2 = std::max(tl2, l2);
         }
+        kt[j] = 2.0 * (1e-9 * tl2 + 1e-10) * 1.000001;
     }
+    // A few long triangles must not inflate the boxes of all the others: the list's working coefficient is that
+    // of its 75th-percentile triangle, and the boxes of the triangles above it are inflated here by the difference
+    // times g0, the largest ray factor the working coefficient is used for (other rays use the list's maximum).
+    double ktyp;
+    {
+        std::vector<double> srt(kt);
+        const size_t at = (size_t)(0.75 * (double)(count - 1));
+        std::nth_element(srt.begin(), srt.begin() + at, srt.end());
+        ktyp = srt[at];
+    }
+    for (int j = 0; j < count; j++)
+        if (kt[j] > ktyp) {
+            const double grow = (kt[j] - ktyp) * g0 * 1.000001;
+            for (int k = 0; k < 3; k++) { bt[j].lo[k] -= grow; bt[j].hi[k] += grow; }
+        }
     CullBuild B = {&cull, &bt, cull_base, tri_base, first, 0};
     double lo[3], hi[3];
     cull_fill(B, 0, count, 1, li, lo, hi);
     max_depth = std::max(max_depth, B.max_depth);
     for (int j = 0; j < count; j++) order[first + j] = bt[j].src;
-    float kf = f_up(2.0 * (1e-9 * lmax2 + 1e-10) * 1.000001); // the list's margin coefficient, rounded up
+    float kf = f_up(2.0 * (1e-9 * lmax2 + 1e-10) * 1.000001); // the list's largest margin coefficient, rounded up
     if (!(kf >= 0.0f)) kf = INFINITY;
-    memcpy(&hdr.meta, &kf, 4);
+    float kw = f_up(ktyp);
+    if (!(kw >= 0.0f) || !std::isfinite(g0)) kw = kf;
+    unsigned bits;
+    memcpy(&bits, &kw, 4);
+    bits = (bits + 0xFFu) & 0xFFFFFF00u; // rounded up to 16 mantissa bits
+    memcpy(&kw, &bits, 4);
+    unsigned r = 0;
+    while (r < 255 && !(std::ldexp((double)kw, (int)r) >= (double)kf)) r++;
+    hdr.meta = bits | r;
 }
 
 int validate(const rt_scene_desc *D) {
@@ -1524,6 +1555,24 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     std::vector<char> pool(g_cull * 16, 0);
     std::vector<QuadRec> cull;
     std::vector<ListHdr> lhdr((size_t)D->n_nodes);
+    // the ray margin factor up to which a list's working coefficient applies: four times the scene's reach
+    // (summed half extents of the vertex box + longest edge), i.e. every origin within about three scene sizes
+    double g0 = 1.0;
+    {
+        double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, l2max = 0;
+        for (int g = 0; g < D->n_tris; g++) {
+            const double *v = D->tri_verts + 9 * (size_t)g;
+            for (int e = 0; e < 3; e++) {
+                const double *a = v + 3 * e, *b = v + 3 * ((e + 1) % 3);
+                l2max = std::max(l2max, (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+                for (int k = 0; k < 3; k++) {
+                    if (g == 0 && e == 0) lo[k] = hi[k] = a[k];
+                    lo[k] = std::min(lo[k], a[k]); hi[k] = std::max(hi[k], a[k]);
+                }
+            }
+        }
+        g0 += 4.0 * (std::sqrt(l2max) + 0.5 * ((hi[0] - lo[0]) + (hi[1] - lo[1]) + (hi[2] - lo[2])));
+    }
     std::vector<int> order((size_t)D->n_list); // device position -> entry of list_tri
     for (int i = 0; i < D->n_list; i++) order[i] = i;
     int cull_depth = 0;
@@ -1537,7 +1586,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         memset(&li, 0, sizeof(li));
         ListHdr &hdr = lhdr[i];
         const int cnt = D->node_count[i], first = D->node_first[i];
-        if (cnt > SMALL_LIST) build_list(D, first, cnt, order, cull, (unsigned)g_cull, (unsigned)g_tri, li, hdr, cull_depth);
+        if (cnt > SMALL_LIST) build_list(D, first, cnt, order, cull, (unsigned)g_cull, (unsigned)g_tri, li, hdr, cull_depth, g0);
         else {
             hdr.meta = LIST_SHORT | (unsigned)cnt;
             li.item[0] = IT_TRI | IT_CHAIN | ((unsigned)g_tri + 5u * (unsigned)first);
