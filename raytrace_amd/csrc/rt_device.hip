@@ -104,11 +104,21 @@ struct __attribute__((aligned(16))) QuadRec {
     unsigned item[4];
 };
 static_assert(sizeof(QuadRec) == 64, "QuadRec must be 64 bytes");
-// Boxes of a node's two children, quantised like a culling record's (single-precision base, step kept
-// as the upper 16 bits of a float, one byte per plane), so that the parent's step can skip a child
-// whose check_aabb is certain to fail.  Child 0 is the left child.
-struct __attribute__((aligned(16))) KidRec { float base[3]; unsigned short step16[3]; unsigned short pad; unsigned char q[2][3][2]; };
-static_assert(sizeof(KidRec) == 32, "KidRec is two granules");
+// Boxes of a node's two children and of its own list, quantised like a culling record's (single-precision
+// base, step kept as the upper 16 bits of a float, one byte per plane), so that the node's step can skip a
+// child whose check_aabb is certain to fail and an own list no triangle of which the ray can meet.
+// Box 0 is the left child, 1 the right child, 2 the own list (with its ListHdr::meta beside it).
+struct __attribute__((aligned(16))) KidRec {
+    float base[3];
+    unsigned short step16[3];
+    unsigned short flags; // KID_*
+    unsigned char q[3][3][2];
+    unsigned char pad2[2];
+    unsigned meta;        // the own list's margin coefficients (ListHdr::meta)
+    unsigned spare;
+};
+static_assert(sizeof(KidRec) == 48, "KidRec is three granules");
+constexpr unsigned KID_NOKIDS = 1, KID_LIST = 2, KID_EMPTY = 4; // children's boxes unusable; list box usable; own list empty
 
 struct ListHdr { // per node, beside its list record: what the "near child finished" step needs
     unsigned right; // granule of the node's right child (0 = none), for the far-child step
@@ -479,15 +489,36 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             stk[sp & (LDS_STACK - 1)][slot] = item;
             sp++;
         };
+        auto pop = [&]() __attribute__((always_inline)) -> unsigned {
+            if (sp == 0) return IT_END;
+            sp--;
+            if (sp >= slo) return stk[sp & (LDS_STACK - 1)][slot];
+            sp++; // the ring is empty: the level is in HBM and stays there until a refill step
+            return IT_REFILL;
+        };
+        auto is_marker = [](unsigned x) __attribute__((always_inline)) { return (x & (IT_AFTER | 1u)) == (IT_AFTER | 1u) && x != IT_END; };
+        unsigned next = 0;      // the item to continue with, unless the tail is to pop one
+        unsigned vis_add = 0;   // visits that markers count in this step (at most two)
+        // A marker restores the frame's flag; if the near child found nothing, its far child is entered (the marker
+        // carries its granule) or, if that child cannot pass its box, counted as a visit.  Returns "pop the next item".
+        auto do_marker = [&](unsigned m) __attribute__((always_inline)) -> bool {
+            const unsigned fk = (m >> 28) & 3u;
+            const bool near_hit = (st & ST_FLAG) != 0; // what the near child's check() returned
+            if ((m >> 30) & 1u) st |= ST_FLAG;          // back in the enclosing frame
+            if (!near_hit && (fk == 1u || fk == 2u)) { next = m & (IDX28 & ~3u); return false; } // kdtree.cpp:124,133
+            vis_add += (fk == 3u && !near_hit) ? 1u : 0u;
+            return true;
+        };
         // what the step leaves behind for the common tail
         bool want_pop = false;  // take the next item from the stack (or finish the traversal)
-        unsigned next = 0;      // otherwise: the item to continue with
         unsigned push_item = 0; // item to push before that (0 = none; the root is never pushed)
         bool done = false;      // the slot found no more work
         RT_TICK(tk1);
 
         if (pick == K_NODE) {
             const bool refill = run && cur == IT_REFILL;
+            const bool marker = run && is_marker(cur); // a second marker in a row (see the tail)
+            if (marker) want_pop = do_marker(cur);
             unsigned rf[REFILL];
             if (refill) { // issue the loads of levels sp - 1 (the item to continue with), sp - 2, ...
 #pragma unroll
@@ -496,12 +527,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     rf[k] = S.ovf[(unsigned)lv * (unsigned)S.n_slots + gslot0 + (unsigned)slot];
                 }
             }
-            bool skipped = false; // the near child's visit was decided here (it is still a visit of the reference)
-            if (run && !refill) { // ---- enter a node (kdtree.cpp:111-141)
+            bool skipped = false, skipped_far = false; // a child's visit was decided here (it is still a visit of the reference)
+            if (run && !refill && !marker) { // ---- enter a node (kdtree.cpp:111-141)
                 const double2 *p = (const double2 *)(S.pool + (size_t)cur * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                const uint4 *kp = (const uint4 *)(S.pool + (size_t)(2u * S.g_list + (cur >> 1)) * 16); // the children's boxes
-                const uint4 k0 = kp[0], k1 = kp[1];
+                const uint4 *kp = (const uint4 *)(S.pool + (size_t)(2u * S.g_list + 3u * (cur >> 2)) * 16); // boxes of the children and the own list
+                const uint4 k0 = kp[0], k1 = kp[1], k2 = kp[2];
+                const float gfac = sG[slot];
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
                 const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
                 const double mi[3] = {q0.x, q0.y, q1.x}, ma[3] = {q1.y, q2.x, q2.y};
@@ -558,14 +590,22 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     // accepts nothing that misses the child's box grown by `pad` (see above), and the
                     // quantised boxes contain the exact ones, so the single-precision slab test of the
                     // culling records (same expression, same error bound, inflation `pad`) decides it.
+                    // The own list's box (inflated like the boxes of its hierarchy) is tested the same way: a
+                    // list the ray cannot meet, or an empty one, needs no step of its own.
+                    bool list_missed;
                     {
                         typedef float f2 __attribute__((ext_vector_type(2)));
                         const float sf[3] = {(float)s[0], (float)s[1], (float)s[2]};
                         const float ivf[3] = {cull_inv((float)inv[0]), cull_inv((float)inv[1]), cull_inv((float)inv[2])};
-                        const float mt = ((float)(pad * 1.000001) + S.fslack + 9.6e-7f * (fabsf(sf[0]) + fabsf(sf[1]) + fabsf(sf[2]))) * 1.000001f;
+                        const float msl = S.fslack + 9.6e-7f * (fabsf(sf[0]) + fabsf(sf[1]) + fabsf(sf[2]));
                         const float kbase[3] = {__uint_as_float(k0.x), __uint_as_float(k0.y), __uint_as_float(k0.z)};
                         const float kstep[3] = {__uint_as_float(k0.w << 16), __uint_as_float(k0.w & 0xFFFF0000u), __uint_as_float(k1.x << 16)};
-                        const unsigned kq[3] = {k1.y, k1.z, k1.w}; // 12 plane bytes: [child][axis][lower, upper]
+                        const unsigned kq[5] = {k1.y, k1.z, k1.w, k2.x, k2.y}; // 18 plane bytes: [box][axis][lower, upper]
+                        const unsigned kflags = k1.x >> 16;
+                        // the list's inflation, as the step that starts the list would compute it
+                        const float mgl = ldexpf(__uint_as_float(k2.z), gfac < 0.0f ? (int)(k2.z & 0xFFu) : 0) * fabsf(gfac);
+                        // one inflation for all three boxes, the larger of the two (a larger one only skips less)
+                        const float mt = (fmaxf((float)(pad * 1.000001), mgl) + msl) * 1.000001f;
                         f2 ka[3], kb[3];
 #pragma unroll
                         for (int i = 0; i < 3; i++) {
@@ -573,9 +613,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                             ka[i] = (f2){a1, a1};
                             kb[i] = (f2){(kbase[i] - (sf[i] + mt)) * ivf[i], (kbase[i] - (sf[i] - mt)) * ivf[i]};
                         }
-                        bool met[2];
+                        bool met[3];
 #pragma unroll
-                        for (int k = 0; k < 2; k++) {
+                        for (int k = 0; k < 3; k++) {
                             float ta[3], tb[3];
 #pragma unroll
                             for (int i = 0; i < 3; i++) {
@@ -587,17 +627,33 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                                 tb[i] = fmaxf(t.x, t.y);
                             }
                             const float tmin = fmaxf(fmaxf(ta[0], ta[1]), fmaxf(ta[2], 0.0f)), tmax = fminf(fminf(tb[0], tb[1]), tb[2]);
-                            met[k] = (tmin * 0.999999f <= tmax) | ((k1.x >> 16) != 0); // a record marked unusable culls nothing
+                            met[k] = tmin * 0.999999f <= tmax;
                         }
+                        if (kflags & KID_NOKIDS) met[0] = met[1] = true; // boxes marked unusable cull nothing
+                        list_missed = (kflags & KID_EMPTY) != 0 || ((kflags & KID_LIST) != 0 && !met[2]);
                         if (near != 0 && !met[nearL ? 0 : 1]) { near = 0; skipped = true; } // its check() returns false at once
                         if (farkind != 0 && !met[farkind == 1 ? 0 : 1]) farkind = 3;          // likewise, if it comes to that
                     }
                     // the own list and the far child come after the near subtree; the frame's flag
                     // travels in the item and the near subtree starts with a clean one
+                    const unsigned st0 = st;
                     const unsigned after = IT_AFTER | (((st >> 8) & 1u) << 30) | (farkind << 28) | node;
-                    st &= ~ST_FLAG;
-                    if (near != 0) { push_item = after; next = near; }
-                    else next = after;
+                    const unsigned far_item = farkind == 1 ? node + 4 : right;
+                    if (!list_missed) {
+                        st &= ~ST_FLAG;
+                        if (near != 0) { push_item = after; next = near; }
+                        else next = after;
+                    } else if (near != 0) {
+                        // nothing to scan here after the near subtree: a marker (an after item with bit 0 set, which
+                        // the tail of whatever step pops it handles) restores the flag and decides about the far
+                        // child, whose granule it carries in place of the node's
+                        st &= ~ST_FLAG;
+                        push_item = IT_AFTER | (((st0 >> 8) & 1u) << 30) | (farkind << 28) | ((farkind == 1 || farkind == 2) ? far_item : 0u) | 1u;
+                        next = near;
+                    } else { // no near subtree either: check() goes straight to the far child (kdtree.cpp:124,133)
+                        if (farkind == 1 || farkind == 2) next = far_item;
+                        else { skipped_far = farkind == 3; want_pop = true; } // (a far child that fails at its box is only counted)
+                    }
                 }
             }
             if (refill) { // levels [slo', sp - 1) go to the ring, level sp - 1 continues
@@ -608,7 +664,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     if (sp - k >= 0) stk[(sp - k) & (LDS_STACK - 1)][slot] = rf[k];
                 slo = sp - (REFILL - 1) > 0 ? sp - (REFILL - 1) : 0;
             }
-            RT_SCOUNT(c_visits, nrun - (int)__popcll(__ballot(refill)) + (int)__popcll(__ballot(skipped)));
+            RT_SCOUNT(c_visits, nrun - (int)__popcll(__ballot(refill | marker)) + (int)__popcll(__ballot(skipped)) + (int)__popcll(__ballot(skipped_far)));
         } else if (pick == K_CULL) {
             bool boxes = false, far_skipped = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
@@ -1039,21 +1095,15 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         RT_TICK(tk2);
         if (run) {
             if (push_item != 0) push(push_item);
-            if (want_pop) {
-                if (sp == 0) next = IT_END;
-                else {
-                    sp--;
-                    if (sp >= slo) next = stk[sp & (LDS_STACK - 1)][slot];
-                    else { // the ring is empty: the level is in HBM and stays there until a refill step
-                        sp++;
-                        next = IT_REFILL;
-                    }
-                }
-            }
+            // Pop; a marker (see the node step: "the near subtree is done and there is no own list to scan") that
+            // comes up is dealt with on the spot, one per tail -- a second one in a row goes through a node step.
+            if (want_pop) next = pop();
+            if (is_marker(next) && do_marker(next)) next = pop();
         }
+        RT_SCOUNT(c_visits, (unsigned)__popcll(__ballot((vis_add & 1u) != 0)) + 2u * (unsigned)__popcll(__ballot((vis_add & 2u) != 0)));
         // the slot goes on the stack of the kind of step it needs next
         {
-            const unsigned nk = (!run || done) ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
+            const unsigned nk = (!run || done) ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : is_marker(next) ? (unsigned)K_NODE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
             const unsigned long long m0 = __ballot(nk == K_NODE), m1 = __ballot(nk == K_CULL), m2 = __ballot(nk == K_TRI), m3 = __ballot(nk == K_SHADE);
             const unsigned long long mine = nk == K_NODE ? m0 : nk == K_CULL ? m1 : nk == K_TRI ? m2 : m3;
             const int below = nk == K_NODE ? q0 : nk == K_CULL ? q1 : nk == K_TRI ? q2 : q3;
@@ -1276,13 +1326,15 @@ void cull_fill(CullBuild &B, int a, int b, int depth, QuadRec &q, double lo[3], 
     }
 }
 
-// quantises the boxes of the (up to two) children of a node; lo/hi[c] are exact bounds, has[c] says which exist
-void kid_fill(KidRec &kr, const double lo[2][3], const double hi[2][3], const bool has[2]) {
+// quantises the boxes of the (up to two) children of a node and of its own list; lo/hi[c] are exact bounds,
+// has[c] says which exist (c = 2: the list, its box includes what its triangles' boxes were inflated by)
+void kid_fill(KidRec &kr, const double lo[3][3], const double hi[3][3], const bool has[3]) {
     memset(&kr, 0, sizeof(kr));
-    if (!has[0] && !has[1]) return;
+    if (!has[0] && !has[1] && !has[2]) return;
+    bool bad[3] = {false, false, false};
     for (int k = 0; k < 3; k++) {
         double l = 1e300, h = -1e300;
-        for (int c = 0; c < 2; c++)
+        for (int c = 0; c < 3; c++)
             if (has[c]) { l = std::min(l, lo[c][k]); h = std::max(h, hi[c][k]); }
         const float base = f_down(l), top = f_up(h);
         // the step keeps 16 bits: rounded up to the next such value, then raised until 255 steps reach the top
@@ -1298,7 +1350,7 @@ void kid_fill(KidRec &kr, const double lo[2][3], const double hi[2][3], const bo
         }
         kr.base[k] = base;
         kr.step16[k] = (unsigned short)(bits >> 16);
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < 3; c++) {
             int b0 = 0, b1 = 255;
             if (has[c] && st > 0.0f) {
                 b0 = (int)std::floor((lo[c][k] - (double)base) / (double)st);
@@ -1307,20 +1359,22 @@ void kid_fill(KidRec &kr, const double lo[2][3], const double hi[2][3], const bo
                 b1 = (int)std::ceil((hi[c][k] - (double)base) / (double)st);
                 b1 = std::max(0, std::min(255, b1));
                 while (b1 < 255 && (double)fmaf((float)b1, st, base) < hi[c][k]) b1++;
-                // a plane that cannot be placed outside the bound (non-finite or enormous coordinates) disables the axis
-                if ((double)fmaf((float)b0, st, base) > lo[c][k] || (double)fmaf((float)b1, st, base) < hi[c][k]) { kr.pad = 1; }
+                // a plane that cannot be placed outside the bound (non-finite or enormous coordinates) disables the box
+                if (!((double)fmaf((float)b0, st, base) <= lo[c][k]) || !((double)fmaf((float)b1, st, base) >= hi[c][k])) bad[c] = true;
             } else if (has[c]) { // flat union box: every plane is `base`; usable only if that is the exact coordinate
                 b0 = b1 = 0;
-                if ((double)base > lo[c][k] || (double)base < hi[c][k]) kr.pad = 1;
+                if (!((double)base <= lo[c][k]) || !((double)base >= hi[c][k])) bad[c] = true;
             }
             kr.q[c][k][0] = (unsigned char)b0; kr.q[c][k][1] = (unsigned char)b1;
         }
     }
+    if (bad[0] || bad[1]) kr.flags |= KID_NOKIDS;
+    if (has[2] && !bad[2]) kr.flags |= KID_LIST;
 }
 
 // fills the list record of a list longer than SMALL_LIST and permutes order[first..first+count)
 void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<QuadRec> &cull, unsigned cull_base,
-                unsigned tri_base, QuadRec &li, ListHdr &hdr, int &max_depth, double g0) {
+                unsigned tri_base, QuadRec &li, ListHdr &hdr, int &max_depth, double g0, double lbox_lo[3], double lbox_hi[3]) {
     std::vector<CullTri> bt((size_t)count);
     std::vector<double> kt((size_t)count); // margin coefficient 2 * (1e-9 L^2 + 1e-10) of each triangle, L its longest edge
     double lmax2 = 0;
@@ -1358,8 +1412,7 @@ void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &
             for (int k = 0; k < 3; k++) { bt[j].lo[k] -= grow; bt[j].hi[k] += grow; }
         }
     CullBuild B = {&cull, &bt, cull_base, tri_base, first, 0};
-    double lo[3], hi[3];
-    cull_fill(B, 0, count, 1, li, lo, hi);
+    cull_fill(B, 0, count, 1, li, lbox_lo, lbox_hi);
     max_depth = std::max(max_depth, B.max_depth);
     for (int j = 0; j < count; j++) order[first + j] = bt[j].src;
     float kf = f_up(2.0 * (1e-9 * lmax2 + 1e-10) * 1.000001); // the list's largest margin coefficient, rounded up
@@ -1546,9 +1599,9 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (dev < 0 || dev >= ndev) return fail(RT_E_INVALID, "device %d not in [0,%d)", dev, ndev);
     HIP_TRY(hipSetDevice(dev));
 
-    // pool layout in 16-byte granules: nodes (4 each), their list records (4 each), their child-box records (2 each),
+    // pool layout in 16-byte granules: nodes (4 each), their list records (4 each), their child- and list-box records (3 each),
     // triangles (5), cull records (4); how many cull records the hierarchies take is only known once they are built
-    const size_t g_list = 4 * (size_t)D->n_nodes, g_kid = 2 * g_list, g_tri = g_kid + 2 * (size_t)D->n_nodes,
+    const size_t g_list = 4 * (size_t)D->n_nodes, g_kid = 2 * g_list, g_tri = g_kid + 3 * (size_t)D->n_nodes,
                  g_sph = g_tri + 5 * (size_t)D->n_tris, // copies of the spheres (2 granules each) for the sphere hierarchy's leaves
                  g_cull = (g_sph + 2 * (size_t)D->n_spheres + 6) & ~(size_t)3;
     if (g_cull + 4 > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
@@ -1586,22 +1639,28 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         memset(&li, 0, sizeof(li));
         ListHdr &hdr = lhdr[i];
         const int cnt = D->node_count[i], first = D->node_first[i];
-        if (cnt > SMALL_LIST) build_list(D, first, cnt, order, cull, (unsigned)g_cull, (unsigned)g_tri, li, hdr, cull_depth, g0);
-        else {
+        double klo[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, khi[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        bool has[3] = {false, false, false};
+        if (cnt > SMALL_LIST) {
+            build_list(D, first, cnt, order, cull, (unsigned)g_cull, (unsigned)g_tri, li, hdr, cull_depth, g0, klo[2], khi[2]);
+            has[2] = true;
+        } else {
             hdr.meta = LIST_SHORT | (unsigned)cnt;
             li.item[0] = IT_TRI | IT_CHAIN | ((unsigned)g_tri + 5u * (unsigned)first);
         }
         hdr.right = n.right;
         {
             KidRec kr;
-            double klo[2][3] = {{0, 0, 0}, {0, 0, 0}}, khi[2][3] = {{0, 0, 0}, {0, 0, 0}};
             const int kid[2] = {D->node_left[i] >= 0 ? i + 1 : -1, D->node_right[i] > 0 ? D->node_right[i] : -1};
-            const bool has[2] = {kid[0] >= 0, kid[1] >= 0};
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < 2; c++) {
+                has[c] = kid[c] >= 0;
                 if (has[c])
                     for (int k = 0; k < 3; k++) { klo[c][k] = D->node_box[6 * (size_t)kid[c] + k]; khi[c][k] = D->node_box[6 * (size_t)kid[c] + 3 + k]; }
+            }
             kid_fill(kr, klo, khi, has);
-            memcpy(&pool[(g_kid + 2 * (size_t)i) * 16], &kr, 32);
+            if (cnt == 0) kr.flags |= KID_EMPTY;
+            kr.meta = hdr.meta;
+            memcpy(&pool[(g_kid + 3 * (size_t)i) * 16], &kr, 48);
         }
         memcpy(&pool[(size_t)i * 64], &n, 64);
         memcpy(&pool[(g_list + 4 * (size_t)i) * 16], &li, 64);
@@ -1711,7 +1770,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->grid = pr.multiProcessorCount * per_cu;
     const int n_slots = s->grid * SLOTS;
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
-    const int need_depth = D->tree_depth + 3 * cull_depth + 4 + (sph_root ? 1 : 0);
+    const int need_depth = D->tree_depth + 3 * cull_depth + 5 + (sph_root ? 1 : 0);
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK + 1 : 0; // levels that can move to HBM
     if ((long long)ovf_depth * n_slots >= (1ll << 31)) {
         rt_free_scene(s);
