@@ -23,15 +23,15 @@
 // type), and per ray slot a column of 8-byte words (direction, best hit, shading state).
 //
 // Execution: a persistent grid of one-wavefront workgroups.  Each wavefront owns 128 ray slots
-// (one pixel's current path each); slots take pixels from an atomic counter in 8x8-block order
-// and run the pixel's 4*samps paths to completion, so the per-pixel sums happen in the
-// reference's order with no atomics.  See k_main for the scheduling.
+// (one sub-pixel's current path each); slots take sub-pixels from an atomic counter in 8x8-block
+// order, a pixel's four always in one wavefront, and the one that finishes last adds the four
+// shares in the reference's order.  See k_main for the scheduling.
 //
-// Long own lists.  The reference tests EVERY triangle of a visited node's own list, and its
+// Own lists.  The reference tests EVERY triangle of a visited node's own list, and its
 // median-split tree leaves thousands of straddling triangles on the top nodes.  Testing them all
 // is not needed to get the same answer: check_node's result is "smallest t > eps, first in list
 // order among equals" plus "does any t < 1e10 exist", and both only depend on the triangles that
-// Polygon::intersect accepts.  So each long list gets a small bounding-box hierarchy, built at
+// Polygon::intersect accepts.  So each list of two or more triangles gets a bounding-box hierarchy, built at
 // upload, whose boxes are inflated by a margin that provably exceeds how far outside a triangle
 // the floating-point Moller-Trumbore test can still accept a ray (see ray_margin_factor()); subtrees
 // whose inflated box the ray misses are skipped, the surviving triangles go through the unchanged
@@ -75,15 +75,17 @@ constexpr int N_STATS = 9;
 #ifndef RT_SMALL_LIST
 #define RT_SMALL_LIST 1
 #endif
-constexpr int SMALL_LIST = RT_SMALL_LIST;
-constexpr int SPH_HIER_MIN = 16; // scenes with at least this many spheres get a hierarchy over them // own lists up to this length are tested directly, longer ones get a hierarchy
+constexpr int SMALL_LIST = RT_SMALL_LIST; // own lists up to this length are tested directly, longer ones get a hierarchy
+constexpr int SPH_HIER_MIN = 16; // scenes with at least this many spheres get a hierarchy over them
 
 // Every traversal record lives in ONE pool addressed in 16-byte granules, and a work item carries
 // the granule of its record:
 //   node i        granule 4*i             NodeRec (64 B)
 //   its own list  granule g_list + 4*i    QuadRec (64 B): the list's start (+ an 8-byte ListHdr in its own array)
-//   cull record   4 granules              QuadRec (64 B)
+//   its boxes     granule 2*g_list + 3*i  KidRec (48 B): children and own list, for the node's step
 //   triangle      5 granules              TriRec (80 B)
+//   sphere        2 granules              centre, radius (leaves of the sphere hierarchy)
+//   cull record   4 granules              QuadRec (64 B)
 struct __attribute__((aligned(16))) NodeRec { // one kd-tree node (KdTree, kdtree.h:96-116)
     double mi[3], ma[3];
     double split;
