@@ -271,6 +271,33 @@ def test_edge_scenes(ra, po):
     dev.close()
 
 
+@pytest.mark.parametrize("name", ["bunny5k", "sponza40k"])
+def test_far_origins_and_long_directions(world, name):
+    """Rays that start many scene sizes away, and directions much longer or shorter than one: the
+    culling boxes then use each list's largest margin coefficient instead of the working one (the
+    inflation built into the boxes at upload only covers origins within a few scene sizes)."""
+    w = world[name]
+    rs = np.random.RandomState(23)
+    n = 4000
+    target = w["center"] + rs.uniform(-0.6, 0.6, (n, 3)) * w["spread"]
+    away = rs.normal(size=(n, 3))
+    away /= np.linalg.norm(away, axis=1, keepdims=True)
+    dist = 10.0 ** rs.uniform(0.5, 4.0, (n, 1)) * w["spread"]  # 3 .. 10 000 scene sizes
+    o = target + away * dist
+    d = (target - o) / np.linalg.norm(target - o, axis=1, keepdims=True)
+    d[n // 2:] *= 10.0 ** rs.uniform(-3, 3, (n - n // 2, 1))     # not unit length
+    o[n // 2:] = target[n // 2:] + away[n // 2:] * rs.uniform(1, 3, (n - n // 2, 1)) * w["spread"]
+    rays = np.concatenate([o, d], 1)
+    tid, tt, sid, st, stats = w["dev"].trace_rays(rays)
+    otid, ott, osid, ost, ostats = w["orc"].trace(rays)
+    assert np.array_equal(tid, otid)
+    assert np.array_equal(tt, ott)
+    assert np.array_equal(sid, osid)
+    assert np.array_equal(st, ost)
+    assert {k: stats[k] for k in ostats} == ostats
+    assert (tid >= 0).sum() > n // 10
+
+
 def test_sphere_hierarchy_matches_brute_force_scan(ra, po):
     """Scenes with 16 or more spheres search them through a hierarchy after the kd-tree; the reference
     scans all of them (sphere.cpp:3-14).  Same ids, distances and work counters as the oracle for random
