@@ -649,8 +649,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                         // nothing to scan here after the near subtree: a marker (an after item with bit 0 set, which
                         // the tail of whatever step pops it handles) restores the flag and decides about the far
                         // child, whose granule it carries in place of the node's
+                        // (a marker with no far child and a clear flag to restore would do nothing: none is pushed)
                         st &= ~ST_FLAG;
-                        push_item = IT_AFTER | (((st0 >> 8) & 1u) << 30) | (farkind << 28) | ((farkind == 1 || farkind == 2) ? far_item : 0u) | 1u;
+                        if (farkind != 0 || (st0 & ST_FLAG) != 0)
+                            push_item = IT_AFTER | (((st0 >> 8) & 1u) << 30) | (farkind << 28) | ((farkind == 1 || farkind == 2) ? far_item : 0u) | 1u;
                         next = near;
                     } else { // no near subtree either: check() goes straight to the far child (kdtree.cpp:124,133)
                         if (farkind == 1 || farkind == 2) next = far_item;
