@@ -491,12 +491,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             stk[sp & (LDS_STACK - 1)][slot] = item;
             sp++;
         };
-        auto pop = [&]() __attribute__((always_inline)) -> unsigned {
-            if (sp == 0) return IT_END;
-            sp--;
-            if (sp >= slo) return stk[sp & (LDS_STACK - 1)][slot];
-            sp++; // the ring is empty: the level is in HBM and stays there until a refill step
-            return IT_REFILL;
+        auto pop = [&]() __attribute__((always_inline)) -> unsigned { // (without branches: the read is harmless when not used)
+            const unsigned e = stk[(sp - 1) & (LDS_STACK - 1)][slot];
+            const bool in_ring = sp > slo;
+            // the ring is empty: the level is in HBM and stays there until a refill step
+            const unsigned r = sp == 0 ? IT_END : in_ring ? e : IT_REFILL;
+            sp -= in_ring ? 1 : 0;
+            return r;
         };
         auto is_marker = [](unsigned x) __attribute__((always_inline)) { return (x & (IT_AFTER | 1u)) == (IT_AFTER | 1u) && x != IT_END; };
         unsigned next = 0;      // the item to continue with, unless the tail is to pop one
@@ -1097,7 +1098,16 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             // Pop; a marker (see the node step: "the near subtree is done and there is no own list to scan") that
             // comes up is dealt with on the spot, one per tail -- a second one in a row goes through a node step.
             if (want_pop) next = pop();
-            if (is_marker(next) && do_marker(next)) next = pop();
+            if (is_marker(next)) { // (without inner branches: the level below is read whether or not it is taken)
+                const unsigned m = next, fk = (m >> 28) & 3u;
+                const bool near_hit = (st & ST_FLAG) != 0, take_far = !near_hit && (fk == 1u || fk == 2u);
+                st |= ((m >> 30) & 1u) << 8; // ST_FLAG: back in the enclosing frame
+                vis_add += (fk == 3u && !near_hit) ? 1u : 0u;
+                const unsigned e = stk[(sp - 1) & (LDS_STACK - 1)][slot];
+                const bool in_ring = sp > slo;
+                next = take_far ? (m & (IDX28 & ~3u)) : sp == 0 ? IT_END : in_ring ? e : IT_REFILL;
+                sp -= (!take_far && in_ring) ? 1 : 0;
+            }
         }
         RT_SCOUNT(c_visits, (unsigned)__popcll(__ballot((vis_add & 1u) != 0)) + 2u * (unsigned)__popcll(__ballot((vis_add & 2u) != 0)));
         // the slot goes on the stack of the kind of step it needs next
