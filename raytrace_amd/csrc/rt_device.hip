@@ -642,23 +642,22 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const unsigned st0 = st;
                     const unsigned after = IT_AFTER | (((st >> 8) & 1u) << 30) | (farkind << 28) | node;
                     const unsigned far_item = farkind == 1 ? node + 4 : right;
-                    if (!list_missed) {
-                        st &= ~ST_FLAG;
-                        if (near != 0) { push_item = after; next = near; }
-                        else next = after;
-                    } else if (near != 0) {
-                        // nothing to scan here after the near subtree: a marker (an after item with bit 0 set, which
-                        // the tail of whatever step pops it handles) restores the flag and decides about the far
-                        // child, whose granule it carries in place of the node's
-                        // (a marker with no far child and a clear flag to restore would do nothing: none is pushed)
-                        st &= ~ST_FLAG;
-                        if (farkind != 0 || (st0 & ST_FLAG) != 0)
-                            push_item = IT_AFTER | (((st0 >> 8) & 1u) << 30) | (farkind << 28) | ((farkind == 1 || farkind == 2) ? far_item : 0u) | 1u;
-                        next = near;
-                    } else { // no near subtree either: check() goes straight to the far child (kdtree.cpp:124,133)
-                        if (farkind == 1 || farkind == 2) next = far_item;
-                        else { skipped_far = farkind == 3; want_pop = true; } // (a far child that fails at its box is only counted)
-                    }
+                    // (written as selects: three cases)
+                    //  * the list has to be scanned: after item under the near subtree, or next if there is none;
+                    //  * nothing to scan after the near subtree: a marker (an after item with bit 0 set, which the
+                    //    tail of whatever step pops it handles) restores the flag and decides about the far child,
+                    //    whose granule it carries in place of the node's -- unless it would have nothing to do
+                    //    (no far child, clear flag to restore);
+                    //  * no near subtree either: check() goes straight to the far child (kdtree.cpp:124,133), and a
+                    //    far child that fails at its box is only counted.
+                    const bool has_near = near != 0, far12 = farkind == 1 || farkind == 2;
+                    const unsigned marker = IT_AFTER | (((st0 >> 8) & 1u) << 30) | (farkind << 28) | (far12 ? far_item : 0u) | 1u;
+                    const bool want_marker = farkind != 0 || (st0 & ST_FLAG) != 0;
+                    if (!list_missed || has_near) st &= ~ST_FLAG;
+                    push_item = !has_near ? 0u : !list_missed ? after : want_marker ? marker : 0u;
+                    next = has_near ? near : !list_missed ? after : far12 ? far_item : 0u;
+                    skipped_far = list_missed && !has_near && farkind == 3;
+                    want_pop = list_missed && !has_near && !far12;
                 }
             }
             if (refill) { // levels [slo', sp - 1) go to the ring, level sp - 1 continues
