@@ -22,7 +22,7 @@
 // id; touched only on the chosen hit), SphGeom 32 B (centre, radius), SphShade 64 B (lig, col,
 // type), and per ray slot a column of 8-byte words (direction, best hit, shading state).
 //
-// Execution: a persistent grid of one-wavefront workgroups.  Each wavefront owns 128 ray slots
+// Execution: a persistent grid of one-wavefront workgroups.  Each wavefront owns 140 ray slots
 // (one sub-pixel's current path each); slots take sub-pixels from an atomic counter in 8x8-block
 // order, a pixel's four always in one wavefront, and the one that finishes last adds the four
 // shares in the reference's order.  See k_main for the scheduling.
@@ -57,14 +57,17 @@ namespace {
 
 constexpr double EPS = 1e-5;  // point.h:7
 constexpr int WAVE = 64;          // threads per workgroup: one wavefront
-#ifndef RT_RAYS_PER_LANE
-#define RT_RAYS_PER_LANE 2
+#ifndef RT_SLOTS
+#define RT_SLOTS 140
 #endif
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK 8
 #endif
-constexpr int RAYS_PER_LANE = RT_RAYS_PER_LANE; // ray slots per lane of the owning wavefront
-constexpr int SLOTS = WAVE * RAYS_PER_LANE; // ray slots per workgroup
+// Ray slots per workgroup (64 to 256).  LDS is handed out in pieces of 1280 bytes: 140 slots of 100 bytes are the
+// most that leave room for eleven wavefronts per CU, and with equally many wavefronts more slots mean fuller steps.
+constexpr int SLOTS = RT_SLOTS;
+// a wavefront's slots in the per-slot arrays in HBM: whole 128-byte lines, so that no two wavefronts write one line
+constexpr int SLOT_STRIDE = (SLOTS + 31) & ~31;
 constexpr int LDS_STACK = RT_LDS_STACK; // the newest traversal-stack levels are kept in LDS (a ring, a power of two), older ones in HBM
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 #ifdef RT_PROFILE
@@ -150,6 +153,7 @@ static_assert(sizeof(SphShade) == 64, "SphShade must be 64 bytes");
 struct DevScene {
     const char *pool; // nodes + lists, cull records, triangles
     const TriShade *tshade;
+    const uint2 *tlist; // per triangle (device position): first list position of its own list, its own list position
     const SphGeom *sph;
     const SphShade *sshade;
     unsigned *ovf;  // overflow stack [ovf_depth][n_slots]
@@ -358,10 +362,9 @@ enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, S
 //   LS_PEND parked glass branches, PEND_WORDS each: origin, direction, throughput, depth | into << 32
 //   LS_V    ray direction;  LS_BT best distance so far
 //   LS_HA   low: best triangle (TriShade index)
-//   LS_HB   best triangle's list rank (low) and list (high)
 //   LS_ST   nearest sphere's distance, LS_SI its index (-1 none, -2: not searched through the hierarchy)
 enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13, LS_OUT = 14, LS_V = 15, LS_BT = 18, LS_HA = 19,
-       LS_HB = 20, LS_ST = 21, LS_SI = 22, LS_PEND = 23 };
+       LS_ST = 20, LS_SI = 21, LS_PEND = 22 };
 constexpr int PEND_WORDS = 10;
 constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
 // per-slot flags word in LDS: stack depth (bits 0-7), the frame's "has a hit" flag (8), the kind
@@ -376,11 +379,11 @@ constexpr int ST_KIND = 9, ST_LO = 12;
 //            also does the bookkeeping of "the node's near child has returned"   (kdtree.cpp:122-125)
 //     tri    one exact triangle test                                            (kdtree.cpp:101-107)
 //     shade  sphere scan, material, next ray / next path / next pixel           (raytrace.cpp:41-95,196-205)
-// A workgroup is ONE wavefront that owns SLOTS = 128 ray slots.  A slot is a complete path tracer
+// A workgroup is ONE wavefront that owns SLOTS = 140 ray slots.  A slot is a complete path tracer
 // state: its ray origin and inverse direction, its current item, flags and the top of its
 // traversal stack live in LDS, the rest (direction, best hit, shading state) in HBM, and NOTHING
 // about a ray is held in registers between steps.  Each iteration the wavefront votes for the kind
-// of step most of its 128 slots wait for, the (up to 64) slots of that kind are handed to the
+// of step most of its slots wait for, the (up to 64) slots of that kind are handed to the
 // lanes in slot order, every such lane runs the step for its slot (state from LDS, record from the
 // pool, both loads issued together) and writes back the few words that changed.  Because the 64
 // rays of a packet diverge completely after the first bounce, this keeps most lanes active per
@@ -389,6 +392,9 @@ constexpr int ST_KIND = 9, ST_LO = 12;
 // TRACE = false: slots pull pixels (8x8 blocks, one slot per pixel) from an atomic counter and
 // run each pixel's 4*samps paths in the reference's order.  TRACE = true: slots pull explicit rays
 // and report the nearest triangle / sphere (raytrace.cpp:46-47).
+// a float kept in 16 bits: sign, exponent and the top 7 mantissa bits, the magnitude rounded up
+__device__ __forceinline__ unsigned short half_up_put(float x) { return (unsigned short)((__float_as_uint(x) + 0xFFFFu) >> 16); }
+__device__ __forceinline__ float half_up_get(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30f), 1e30f); }
 
 // SPH = true: the scene has a sphere hierarchy (a second instance, so that scenes without one do not pay for it).
@@ -401,15 +407,16 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     __shared__ double2 sA[SLOTS]; // origin x, y
     __shared__ double2 sB[SLOTS]; // origin z, 1/direction x
     __shared__ double2 sC[SLOTS]; // 1/direction y, z
-    __shared__ float sM[SLOTS];   // inflation of the current list's culling boxes
-    __shared__ float sG[SLOTS];   // the ray's margin factor
-    __shared__ unsigned sL[SLOTS]; // current list (node granule)
+    // (both kept as the upper half of a float with the magnitude rounded up: a larger margin only culls less)
+    __shared__ unsigned short sM[SLOTS]; // inflation of the current list's culling boxes
+    __shared__ unsigned short sG[SLOTS]; // the ray's margin factor
     __shared__ unsigned stk[LDS_STACK][SLOTS];
     // the slots that wait for a step, one stack per kind: slot | flags word << 8; item.  Two stacks share an
     // array and grow towards each other (a slot is in at most one of them): node up from 0 and cull down from
     // SLOTS - 1, tri up from SLOTS and shade down from 2 * SLOTS - 1
     __shared__ uint2 sQ[2 * SLOTS];
     static_assert(SLOTS <= 256, "a slot index is kept in 8 bits");
+    static_assert(SLOT_STRIDE % 32 == 0 && SLOT_STRIDE >= SLOTS, "a wavefront's 4-byte columns of the HBM state start on a cache line");
 #ifdef RT_LDS_PAD // occupancy experiments: unused LDS that the compiler cannot drop
     __shared__ unsigned lds_pad[RT_LDS_PAD / 4];
     if (n_work == 0xFFFFFFFFu) { lds_pad[threadIdx.x] = n_work; __syncthreads(); n_work = lds_pad[threadIdx.x ^ 1]; }
@@ -418,13 +425,12 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     auto qindex = [](int kind, int i) __attribute__((always_inline)) { return (kind >> 1) * SLOTS + ((kind & 1) ? SLOTS - 1 - i : i); };
     const size_t lss = (size_t)S.n_slots;
-    const unsigned gslot0 = blockIdx.x * SLOTS;
+    const unsigned gslot0 = blockIdx.x * SLOT_STRIDE;
 
     // all slots start as "nothing traced yet, needs work"
-#pragma unroll
-    for (int r = 0; r < RAYS_PER_LANE; r++) {
-        S.lstate[LS_PST * lss + gslot0 + lane + r * WAVE] = 0.0;
-        sQ[qindex(K_SHADE, lane + r * WAVE)] = make_uint2((unsigned)(lane + r * WAVE), 0u);
+    for (int i = lane; i < SLOTS; i += WAVE) {
+        S.lstate[LS_PST * lss + gslot0 + i] = 0.0;
+        sQ[qindex(K_SHADE, i)] = make_uint2((unsigned)i, 0u);
     }
     int q0 = 0, q1 = 0, q2 = 0, q3 = SLOTS; // entries on the four stacks
     // pieces of work taken from the counter and not handed to a slot yet: first piece, count (in LDS because only
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 const uint4 *kp = (const uint4 *)(S.pool + (size_t)(2u * S.g_list + 3u * (cur >> 2)) * 16); // boxes of the children and the own list
                 const uint4 k0 = kp[0], k1 = kp[1], k2 = kp[2];
-                const float gfac = sG[slot];
+                const float gfac = half_up_get(sG[slot]);
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
                 const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
                 const double mi[3] = {q0.x, q0.y, q1.x}, ma[3] = {q1.y, q2.x, q2.y};
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 uint2 hdr = make_uint2(0u, 0u);
                 if (cur & IT_AFTER) hdr = *(const uint2 *)(S.lhdr + ((cur & IDX28) >> 2)); // right child, list header
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
-                float mg = sM[slot];
+                float mg = half_up_get(sM[slot]);
                 boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
                     const unsigned right = hdr.x, meta = hdr.y;
@@ -687,16 +693,15 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
                     if (farkind == 3) far_skipped = !near_hit; // the far child's check() fails at its box: a visit, nothing else
                     else if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list
-                    sL[slot] = node;                                     // the list now being scanned
                     if (meta & LIST_SHORT) { // up to SMALL_LIST triangles: a chain of tri steps in list order
                         boxes = false;
                         if ((meta & 0xFF) == 0) want_pop = true;
                         else next = it.x;
                     } else { // inflation of this list's boxes, see ray_margin_factor(); a larger one only culls less
-                        const float gfac = sG[slot]; // negative for a ray from far outside the scene: the larger coefficient
+                        const float gfac = half_up_get(sG[slot]); // negative for a ray from far outside the scene: the larger coefficient
                         // (the exponent in the low mantissa bits only makes the coefficient a little larger)
                         mg = ldexpf(__uint_as_float(meta), gfac < 0.0f ? (int)(meta & 0xFFu) : 0) * fabsf(gfac);
-                        sM[slot] = mg;
+                        { const unsigned short h = half_up_put(mg); sM[slot] = h; mg = half_up_get(h); }
                     }
                 }
                 if (SPH && !(cur & IT_AFTER) && (cur & IT_CHAIN)) { // root of the sphere hierarchy: the kd-tree is done
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const double gs = fabs(a.x - S.sph_cen[0]) + fabs(a.y - S.sph_cen[1]) + fabs(b.x - S.sph_cen[2]) + S.sph_h;
                     const float gsf = (float)gs * 1.000001f;
                     mg = S.sph_k * gsf * gsf + S.sph_c;
-                    sM[slot] = mg;
+                    { const unsigned short h = half_up_put(mg); sM[slot] = h; mg = half_up_get(h); }
                 }
                 if (boxes) {
                     // Slab test of the four inflated boxes in single precision, two planes per packed
@@ -791,7 +796,6 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const long long w9 = __double_as_longlong(q4.y);
                 const d3 d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
                 const double best_t = ls[LS_BT * lss];
-                const unsigned cur_list = sL[slot];
                 const double2 a = sA[slot], b = sB[slot];
                 const d3 o = mk(a.x, a.y, b.x);
                 is_sph = SPH && (cur & IDX28) >= S.g_sph;
@@ -822,14 +826,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     // strict < keeps the earlier of two equal distances; inside one list "earlier"
                     // is the lower rank, across lists it is the list visited first
                     bool better = t < best_t;
-                    if (t == best_t) { // rare: the best triangle's list and rank decide
-                        const unsigned long long hb = (unsigned long long)__double_as_longlong(ls[LS_HB * lss]);
-                        better = (unsigned)(hb >> 32) == cur_list && rk < (int)(unsigned)hb;
+                    if (t == best_t && t < 1e20) { // rare: the two triangles' lists and ranks decide
+                        const uint2 lb = S.tlist[((const unsigned *)&ls[LS_HA * lss])[0]], lc = S.tlist[(unsigned)w9 & ~TRI_LAST];
+                        better = lb.x == lc.x && rk < (int)lb.y;
                     }
                     if (better) {
                         ls[LS_BT * lss] = t;
                         ls[LS_HA * lss] = __longlong_as_double((long long)(unsigned long long)((unsigned)w9 & ~TRI_LAST));
-                        ls[LS_HB * lss] = __longlong_as_double((long long)((unsigned long long)(unsigned)rk | ((unsigned long long)cur_list << 32)));
                     }
                     if (t < 1e10) st |= ST_FLAG;
                 }
@@ -1069,10 +1072,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     ls[LS_V * lss] = rd.x; ls[(LS_V + 1) * lss] = rd.y; ls[(LS_V + 2) * lss] = rd.z;
                     ls[LS_BT * lss] = 1e20;
                     ls[LS_HA * lss] = __longlong_as_double(-1ll);                   // no triangle
-                    ls[LS_HB * lss] = __longlong_as_double((long long)0xFFFFFFFE00000000ull); // a list that is never current
-                    sL[slot] = 0xFFFFFFFFu;
                     // negative: beyond the factor (4 * reach + 1 at upload) that the lists' working coefficients cover
-                    sG[slot] = gf <= (float)(3.9 * S.reach) ? gf : -gf;
+                    sG[slot] = half_up_put(gf <= (float)(3.9 * S.reach) ? gf : -gf);
                     st = 0;
                     sp = 0; slo = 0;
                     if (SPH) { // many spheres: their hierarchy is searched after the kd-tree, from the bottom of the stack
@@ -1172,7 +1173,7 @@ int fail(int code, const char *fmt, ...) {
 struct rt_scene {
     int dev = 0;
     DevScene d{};
-    void *pool = nullptr, *tshade = nullptr, *sph = nullptr, *sshade = nullptr;
+    void *pool = nullptr, *tshade = nullptr, *tlist = nullptr, *sph = nullptr, *sshade = nullptr;
     void *ovf = nullptr, *lstate = nullptr, *lhdr = nullptr;
     int tree_depth = 0;
     int grid = 0;               // persistent workgroups
@@ -1735,6 +1736,10 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         if (D->node_count[i] > 0) last[(size_t)D->node_first[i] + D->node_count[i] - 1] = 1;
     double blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0}, lg2 = 0; // vertex box and longest edge of the scene
     std::vector<TriShade> tsh((size_t)D->n_tris);
+    std::vector<unsigned> list_first((size_t)D->n_list, 0); // by list position: where its own list starts
+    for (int i = 0; i < D->n_nodes; i++)
+        for (int k = 0; k < D->node_count[i]; k++) list_first[(size_t)D->node_first[i] + k] = (unsigned)D->node_first[i];
+    std::vector<uint2> tls((size_t)D->n_list);
     for (int pos = 0; pos < D->n_list; pos++) {
         const int rank = order[pos];
         const int g = D->list_tri[rank];
@@ -1755,6 +1760,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         }
         t.pos = (int)((unsigned)pos | (last[pos] ? TRI_LAST : 0u));
         t.rank = rank;
+        tls[pos] = make_uint2(list_first[rank], (unsigned)rank);
         memcpy(&pool[(g_tri + 5 * (size_t)pos) * 16], &t, sizeof(t));
         TriShade &h = tsh[pos];
         for (int k = 0; k < 3; k++) {
@@ -1782,6 +1788,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     rc = upload(&s->pool, pool);
     if (!rc) rc = upload(&s->lhdr, lhdr);
     if (!rc) rc = upload(&s->tshade, tsh);
+    if (!rc) rc = upload(&s->tlist, tls);
     if (!rc) rc = upload(&s->sph, sg);
     if (!rc) rc = upload(&s->sshade, ss);
     if (rc) { rt_free_scene(s); return rc; }
@@ -1793,7 +1800,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_main<false, true>), WAVE, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
     s->grid = pr.multiProcessorCount * per_cu;
-    const int n_slots = s->grid * SLOTS;
+    const int n_slots = s->grid * SLOT_STRIDE;
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
     const int need_depth = D->tree_depth + 3 * cull_depth + 5 + (sph_root ? 1 : 0);
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK + 1 : 0; // levels that can move to HBM
@@ -1819,6 +1826,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     }
     s->d.pool = (const char *)s->pool;
     s->d.tshade = (const TriShade *)s->tshade;
+    s->d.tlist = (const uint2 *)s->tlist;
     s->d.sph = (const SphGeom *)s->sph;
     s->d.sshade = (const SphShade *)s->sshade;
     s->d.ovf = (unsigned *)s->ovf;
@@ -1855,7 +1863,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->sph, s->sshade, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile};
+    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);

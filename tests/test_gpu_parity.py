@@ -271,6 +271,48 @@ def test_edge_scenes(ra, po):
     dev.close()
 
 
+def test_equal_distances_across_own_lists(ra, po):
+    """Coplanar overlapping triangles of very different size sit in different own lists (the large
+    ones straddle split planes and stay on interior nodes); an axis-parallel ray meets a small and
+    a large one at exactly the same distance.  Within a list the earlier entry wins, across lists
+    the list visited first (kdtree.cpp:105 with its strict <)."""
+    from raytrace_amd import scenes
+    rng = np.random.default_rng(11)
+    n = 24
+    small = []
+    for i in range(n):
+        for j in range(n):
+            x, y = i - n / 2, j - n / 2
+            small.append([x, y, 0, x + 1, y, 0, x, y + 1, 0.0])
+            small.append([x + 1, y + 1, 0, x, y + 1, 0, x + 1, y, 0.0])
+    small = np.array(small)
+    big = []
+    for k in range(40):  # large triangles in the same plane, at random places
+        c = rng.uniform(-n / 2, n / 2, 2); r = rng.uniform(2, 9)
+        ang = rng.uniform(0, 2 * np.pi) + np.array([0, 2.1, 4.2])
+        big.append(np.stack([c[0] + r * np.cos(ang), c[1] + r * np.sin(ang), np.zeros(3)], 1).reshape(9))
+    big = np.array(big)
+    perm = rng.permutation(len(small) + len(big))  # list order mixes the two kinds
+    sc = {"meshes": [scenes._mesh(np.concatenate([small, big])[perm], (.5, .5, .5))], "spheres": []}
+    m = 3000
+    rays = np.zeros((m, 6))
+    rays[:, :2] = rng.uniform(-n / 2, n / 2, (m, 2))
+    rays[:, 2] = np.where(np.arange(m) % 2 == 0, 8.0, -8.0)
+    rays[:, 5] = np.where(np.arange(m) % 2 == 0, -1.0, 1.0)
+    hs = ra.HostScene(sc)
+    dev = ra.DeviceScene(hs, 0)
+    orc = po.OracleScene(sc)
+    a = dev.trace_rays(rays)
+    b = orc.trace(rays)
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(x, y)
+    assert {k: a[4][k] for k in b[4]} == b[4]
+    is_big = perm[np.maximum(a[0], 0)] >= len(small)
+    hit = a[0] >= 0
+    assert hit.mean() > 0.9 and is_big[hit].any() and (~is_big[hit]).any()  # both kinds win ties
+    dev.close()
+
+
 @pytest.mark.parametrize("name", ["bunny5k", "sponza40k"])
 def test_far_origins_and_long_directions(world, name):
     """Rays that start many scene sizes away, and directions much longer or shorter than one: the
