@@ -162,6 +162,7 @@ struct DevScene {
     double reach;  // its summed half extents + the scene's longest triangle edge
     double absn;   // |centre|_1 + summed half extents
     unsigned g_list; // granule of node 0's list record
+    unsigned g_sphc; // granule of the sphere hierarchy's first cull record (the triangles' records lie below it)
     unsigned g_sph;  // granule of sphere 0's copy in the pool (two granules per sphere); tri items from here on are spheres
     unsigned sph_root; // item of the sphere hierarchy's root record, 0 = spheres are scanned in the shade step
     float sph_k, sph_c; // inflation of the sphere boxes: sph_k * (bound on |centre - origin|)^2 + sph_c
@@ -685,6 +686,12 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 if (cur & IT_AFTER) hdr = *(const uint2 *)(S.lhdr + ((cur & IDX28) >> 2)); // right child, list header
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
                 float mg = half_up_get(sM[slot]);
+                // (for an after item the flag of the enclosing frame is restored below: st or the item's bit)
+                // (the sphere hierarchy keeps only the nearest sphere: its boxes are always limited by that distance)
+                const bool sph_boxes = SPH && !(cur & IT_AFTER) && (cur & IDX28) >= S.g_sphc;
+                const bool lim_on = sph_boxes || ((st & ST_FLAG) != 0) || ((cur & IT_AFTER) && ((cur >> 30) & 1));
+                double best_lim = 0.0;
+                if (lim_on) best_lim = ls[(sph_boxes ? LS_ST : LS_BT) * lss];
                 boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
                     const unsigned right = hdr.x, meta = hdr.y;
@@ -743,6 +750,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                         // lower planes move down by mt, upper planes up
                         kb[i] = (f2){(base[i] - (sf[i] + mt)) * ivf[i], (base[i] - (sf[i] - mt)) * ivf[i]};
                     }
+                    // Once the frame has a hit (its check() returns true whatever follows, kdtree.cpp:105-107), a
+                    // triangle can only matter by being nearer than the best one: boxes that the ray enters
+                    // beyond that distance are dropped.  (Equal distances stay: the parameters err towards "met".)
+                    const float tlim = lim_on ? (float)best_lim * 1.000001f : INFINITY;
                     bool hit[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -756,7 +767,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                             ta[i] = fminf(t.x, t.y);
                             tb[i] = fmaxf(t.x, t.y);
                         }
-                        const float tmin = fmaxf(fmaxf(ta[0], ta[1]), fmaxf(ta[2], 0.0f)), tmax = fminf(fminf(tb[0], tb[1]), tb[2]);
+                        const float tmin = fmaxf(fmaxf(ta[0], ta[1]), fmaxf(ta[2], 0.0f)), tmax = fminf(fminf(tb[0], tb[1]), fminf(tb[2], tlim));
                         hit[k] = (tmin * 0.999999f <= tmax) & (item[k] != 0);
                     }
                     // the first child that is met continues, the others go on the stack
@@ -1694,6 +1705,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     // Scenes with many spheres: the same kind of hierarchy over the spheres' boxes, searched after the kd-tree
     // (the reference scans all of them for every ray, sphere.cpp:3-14).  Its root is one more cull record.
     unsigned sph_root = 0;
+    const size_t g_sphc = g_cull + 4 * cull.size();
     float sph_k = 0.0f, sph_c = 0.0f;
     double sph_cen[3] = {0, 0, 0}, sph_h = 0;
     if (D->n_spheres >= SPH_HIER_MIN) {
@@ -1847,6 +1859,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->d.padc = 2.5e-5 + 4e-12 * boxsum;
     s->d.g_list = (unsigned)g_list;
     s->d.g_sph = (unsigned)g_sph;
+    s->d.g_sphc = (unsigned)g_sphc;
     s->d.sph_root = sph_root;
     s->d.sph_k = sph_k; s->d.sph_c = sph_c;
     for (int k = 0; k < 3; k++) s->d.sph_cen[k] = sph_cen[k];
