@@ -371,7 +371,15 @@ constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
 // per-slot flags word in LDS: stack depth (bits 0-7), the frame's "has a hit" flag (8), the kind
 // of step the slot waits for (9-11), number of stack levels that live in HBM only (12-19)
 constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u;
-constexpr int ST_KIND = 9, ST_LO = 12;
+constexpr int ST_LO = 12;
+// Far children that are only counted (their box is certainly missed) when the near subtree returns false need no
+// stack entry if nothing else waits for that return: the frame keeps their number in two bits of its flags word,
+// an after item or marker saves the enclosing frame's number in bits 26-27, and whatever ends the frame (such an
+// item coming off the stack, or the end of the traversal) adds the number to the visits if the frame found nothing.
+constexpr unsigned ST_N = 0x600u;
+constexpr int ST_NSH = 9, IT_NSH = 26;
+// (after items and markers carry a node granule / 2 in bits 1-25; bit 0 marks a marker)
+__device__ __forceinline__ unsigned after_granule(unsigned x) { return (x & 0x03FFFFFEu) << 1; }
 
 // The whole path -- camera ray, KdTree::check without recursion, check_node, sphere scan, radiance()
 // as a loop -- is cut into steps of four kinds:
@@ -444,6 +452,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     // per-lane sum
     unsigned c_rays = 0, c_visits = 0, c_shades = 0, c_done = 0, c_culls = 0, c_iters = 0, c_lanes = 0;
     unsigned long long l_tris = 0;
+    unsigned l_vis = 0; // visits counted by single lanes (far children that are only counted)
     auto flush = [&]() __attribute__((always_inline)) {
         if (lane == 0) {
             if (c_rays) { atomicAdd(gstats + ST_RAYS, (unsigned long long)c_rays); atomicAdd(gstats + ST_SPHS, (unsigned long long)c_rays * (unsigned)S.n_sph); }
@@ -508,15 +517,16 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         };
         auto is_marker = [](unsigned x) __attribute__((always_inline)) { return (x & (IT_AFTER | 1u)) == (IT_AFTER | 1u) && x != IT_END; };
         unsigned next = 0;      // the item to continue with, unless the tail is to pop one
-        unsigned vis_add = 0;   // visits that markers count in this step (at most two)
+        unsigned vis_add = 0;   // visits that this lane counts in this step
         // A marker restores the frame's flag; if the near child found nothing, its far child is entered (the marker
         // carries its granule) or, if that child cannot pass its box, counted as a visit.  Returns "pop the next item".
         auto do_marker = [&](unsigned m) __attribute__((always_inline)) -> bool {
             const unsigned fk = (m >> 28) & 3u;
             const bool near_hit = (st & ST_FLAG) != 0; // what the near child's check() returned
+            vis_add += near_hit ? 0u : ((st >> ST_NSH) & 3u) + (fk == 3u ? 1u : 0u);
+            st = (st & ~ST_N) | (((m >> IT_NSH) & 3u) << ST_NSH);
             if ((m >> 30) & 1u) st |= ST_FLAG;          // back in the enclosing frame
-            if (!near_hit && (fk == 1u || fk == 2u)) { next = m & (IDX28 & ~3u); return false; } // kdtree.cpp:124,133
-            vis_add += (fk == 3u && !near_hit) ? 1u : 0u;
+            if (!near_hit && (fk == 1u || fk == 2u)) { next = after_granule(m); return false; } // kdtree.cpp:124,133
             return true;
         };
         // what the step leaves behind for the common tail
@@ -647,7 +657,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     // the own list and the far child come after the near subtree; the frame's flag
                     // travels in the item and the near subtree starts with a clean one
                     const unsigned st0 = st;
-                    const unsigned after = IT_AFTER | (((st >> 8) & 1u) << 30) | (farkind << 28) | node;
+                    const unsigned pend = (st >> ST_NSH) & 3u; // counted-only far children of the frame so far
+                    const unsigned after = IT_AFTER | (((st >> 8) & 1u) << 30) | (farkind << 28) | (pend << IT_NSH) | (node >> 1);
                     const unsigned far_item = farkind == 1 ? node + 4 : right;
                     // (written as selects: three cases)
                     //  * the list has to be scanned: after item under the near subtree, or next if there is none;
@@ -658,9 +669,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     //  * no near subtree either: check() goes straight to the far child (kdtree.cpp:124,133), and a
                     //    far child that fails at its box is only counted.
                     const bool has_near = near != 0, far12 = farkind == 1 || farkind == 2;
-                    const unsigned marker = IT_AFTER | (((st0 >> 8) & 1u) << 30) | (farkind << 28) | (far12 ? far_item : 0u) | 1u;
-                    const bool want_marker = farkind != 0 || (st0 & ST_FLAG) != 0;
+                    const unsigned marker = IT_AFTER | (((st0 >> 8) & 1u) << 30) | (farkind << 28) | (pend << IT_NSH) | (far12 ? far_item >> 1 : 0u) | 1u;
+                    // (a far child that is only counted joins the frame's number instead, while that has room)
+                    const bool count_only = farkind == 3 && (st0 & ST_FLAG) == 0 && pend < 3u;
+                    const bool want_marker = (farkind != 0 || (st0 & ST_FLAG) != 0) && !count_only;
                     if (!list_missed || has_near) st &= ~ST_FLAG;
+                    if (has_near && list_missed && count_only) st += 1u << ST_NSH;
+                    if (!list_missed || (has_near && want_marker)) st &= ~ST_N; // the item starts a frame of its own
                     push_item = !has_near ? 0u : !list_missed ? after : want_marker ? marker : 0u;
                     next = has_near ? near : !list_missed ? after : far12 ? far_item : 0u;
                     skipped_far = list_missed && !has_near && farkind == 3;
@@ -677,13 +692,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             }
             RT_SCOUNT(c_visits, nrun - (int)__popcll(__ballot(refill | marker)) + (int)__popcll(__ballot(skipped)) + (int)__popcll(__ballot(skipped_far)));
         } else if (pick == K_CULL) {
-            bool boxes = false, far_skipped = false;
+            bool boxes = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
-                const unsigned g = (cur & IT_AFTER) ? S.g_list + (cur & IDX28) : (cur & IDX28);
+                const unsigned g = (cur & IT_AFTER) ? S.g_list + after_granule(cur) : (cur & IDX28);
                 const uint4 *p = (const uint4 *)(S.pool + (size_t)g * 16);
                 const uint4 r0 = p[0], r1 = p[1], r2 = p[2], it = p[3];
                 uint2 hdr = make_uint2(0u, 0u);
-                if (cur & IT_AFTER) hdr = *(const uint2 *)(S.lhdr + ((cur & IDX28) >> 2)); // right child, list header
+                if (cur & IT_AFTER) hdr = *(const uint2 *)(S.lhdr + (after_granule(cur) >> 2)); // right child, list header
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
                 float mg = half_up_get(sM[slot]);
                 // (for an after item the flag of the enclosing frame is restored below: st or the item's bit)
@@ -695,10 +710,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
                     const unsigned right = hdr.x, meta = hdr.y;
-                    const unsigned node = cur & IDX28, farkind = (cur >> 28) & 3;
+                    const unsigned node = after_granule(cur), farkind = (cur >> 28) & 3;
                     const bool near_hit = (st & ST_FLAG) != 0;         // what the near child's check() returned
+                    // the far child's check() fails at its box: a visit, nothing else; likewise those the frame kept count of
+                    vis_add += near_hit ? 0u : ((st >> ST_NSH) & 3u) + (farkind == 3 ? 1u : 0u);
+                    st = (st & ~ST_N) | (((cur >> IT_NSH) & 3u) << ST_NSH);
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
-                    if (farkind == 3) far_skipped = !near_hit; // the far child's check() fails at its box: a visit, nothing else
+                    if (farkind == 3) {}
                     else if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list
                     if (meta & LIST_SHORT) { // up to SMALL_LIST triangles: a chain of tri steps in list order
                         boxes = false;
@@ -798,7 +816,6 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 }
             }
             RT_SCOUNT(c_culls, (unsigned)__popcll(__ballot(boxes)));
-            RT_SCOUNT(c_visits, (unsigned)__popcll(__ballot(far_skipped)));
         } else if (pick == K_TRI) {
             bool is_sph = false;
             if (run) { // ---- one exact triangle test (kdtree.cpp:105)
@@ -1112,15 +1129,20 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             if (is_marker(next)) { // (without inner branches: the level below is read whether or not it is taken)
                 const unsigned m = next, fk = (m >> 28) & 3u;
                 const bool near_hit = (st & ST_FLAG) != 0, take_far = !near_hit && (fk == 1u || fk == 2u);
+                vis_add += near_hit ? 0u : ((st >> ST_NSH) & 3u) + (fk == 3u ? 1u : 0u);
+                st = (st & ~ST_N) | (((m >> IT_NSH) & 3u) << ST_NSH);
                 st |= ((m >> 30) & 1u) << 8; // ST_FLAG: back in the enclosing frame
-                vis_add += (fk == 3u && !near_hit) ? 1u : 0u;
                 const unsigned e = stk[(sp - 1) & (LDS_STACK - 1)][slot];
                 const bool in_ring = sp > slo;
-                next = take_far ? (m & (IDX28 & ~3u)) : sp == 0 ? IT_END : in_ring ? e : IT_REFILL;
+                next = take_far ? after_granule(m) : sp == 0 ? IT_END : in_ring ? e : IT_REFILL;
                 sp -= (!take_far && in_ring) ? 1 : 0;
             }
+            if (next == IT_END) { // the root's frame ends with the traversal
+                vis_add += (st & ST_FLAG) ? 0u : (st >> ST_NSH) & 3u;
+                st &= ~ST_N;
+            }
         }
-        RT_SCOUNT(c_visits, (unsigned)__popcll(__ballot((vis_add & 1u) != 0)) + 2u * (unsigned)__popcll(__ballot((vis_add & 2u) != 0)));
+        l_vis += vis_add;
         // the slot goes on the stack of the kind of step it needs next
         {
             const unsigned nk = (!run || done) ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : is_marker(next) ? (unsigned)K_NODE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
@@ -1129,7 +1151,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             const int below = nk == K_NODE ? q0 : nk == K_CULL ? q1 : nk == K_TRI ? q2 : q3;
             const int at = below + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
             if (nk != K_DONE)
-                sQ[qindex((int)nk, at)] = make_uint2((unsigned)slot | (((st & ST_FLAG) | (unsigned)sp | ((unsigned)slo << ST_LO)) << 8), next == IT_END ? 0u : next);
+                sQ[qindex((int)nk, at)] = make_uint2((unsigned)slot | (((st & (ST_FLAG | ST_N)) | (unsigned)sp | ((unsigned)slo << ST_LO)) << 8), next == IT_END ? 0u : next);
             q0 += __popcll(m0); q1 += __popcll(m1); q2 += __popcll(m2); q3 += __popcll(m3);
         }
 #ifdef RT_PROFILE
@@ -1150,6 +1172,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     flush();
     for (int off = 32; off > 0; off >>= 1) l_tris += __shfl_down(l_tris, off, 64);
     if (lane == 0 && l_tris) atomicAdd(gstats + ST_TRIS, l_tris);
+    unsigned long long vis = l_vis;
+    for (int off = 32; off > 0; off >>= 1) vis += __shfl_down(vis, off, 64);
+    if (lane == 0 && vis) atomicAdd(gstats + ST_VISITS, vis);
 #undef RT_SCOUNT
 }
 
@@ -1741,6 +1766,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     const size_t n_cull = cull.size();
     const size_t g_end = g_cull + 4 * n_cull + 4;
     if (g_end > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
+    if ((size_t)D->n_nodes * 4 > ((size_t)1 << 27)) return fail(RT_E_LIMIT, "too many tree nodes for the 25-bit node field of a stack item");
     pool.resize(g_end * 16, 0);
     if (n_cull) memcpy(&pool[g_cull * 16], cull.data(), n_cull * sizeof(QuadRec));
     std::vector<unsigned char> last((size_t)D->n_list, 0); // device position is the last of its own list
