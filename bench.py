@@ -182,7 +182,7 @@ def main():
                        "parallelism": f"tiles%{world} + gather", "rays_per_frame": rays_total / args.steps},
             "frame_time_ms": elapsed / args.steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_main<false, false>", "kernel_ms_avg": avg_ms,
+                         "traffic": None, "kernel": "k_main<false, false, 152, 4>", "kernel_ms_avg": avg_ms,
                          "per_ray": {"node_visits": per_launch["node_visits"] / max(1, per_launch["rays"]),
                                      "tri_tests_reference": per_launch["tri_tests"] / max(1, per_launch["rays"]),
                                      "tri_tests_done": per_launch["tri_tests_done"] / max(1, per_launch["rays"]),

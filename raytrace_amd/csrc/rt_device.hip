@@ -42,6 +42,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -57,18 +58,26 @@ namespace {
 
 constexpr double EPS = 1e-5;  // point.h:7
 constexpr int WAVE = 64;          // threads per workgroup: one wavefront
+// Two builds of the kernel: ray slots per workgroup (64 to 256) and the newest traversal-stack levels kept in LDS (a
+// ring, a power of two; older levels live in HBM).  LDS is handed out in pieces of 1280 bytes and a slot takes 68 bytes
+// plus 4 per ring level: 152 slots with a 4-level ring are the most that leave room for twelve wavefronts per CU, 140
+// with an 8-level ring for eleven.  With equally many wavefronts more slots mean fuller steps; a deep tree moves too
+// many levels through HBM with the short ring.  RT_SLOTS / RT_LDS_STACK make both builds the same (test builds).
+struct KernelCfg { int slots, ring; };
+#if defined(RT_SLOTS) || defined(RT_LDS_STACK)
 #ifndef RT_SLOTS
 #define RT_SLOTS 140
 #endif
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK 8
 #endif
-// Ray slots per workgroup (64 to 256).  LDS is handed out in pieces of 1280 bytes: 140 slots of 100 bytes are the
-// most that leave room for eleven wavefronts per CU, and with equally many wavefronts more slots mean fuller steps.
-constexpr int SLOTS = RT_SLOTS;
+constexpr KernelCfg CFG_SHALLOW = {RT_SLOTS, RT_LDS_STACK}, CFG_DEEP = {RT_SLOTS, RT_LDS_STACK};
+#else
+constexpr KernelCfg CFG_SHALLOW = {152, 4}, CFG_DEEP = {140, 8};
+#endif
+constexpr int DEEP_TREE = 28; // tree depth from which the 8-level ring is used
 // a wavefront's slots in the per-slot arrays in HBM: whole 128-byte lines, so that no two wavefronts write one line
-constexpr int SLOT_STRIDE = (SLOTS + 31) & ~31;
-constexpr int LDS_STACK = RT_LDS_STACK; // the newest traversal-stack levels are kept in LDS (a ring, a power of two), older ones in HBM
+constexpr int slot_stride(int slots) { return (slots + 31) & ~31; }
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 #ifdef RT_PROFILE
 constexpr int N_STATS = 23; // 9..18: clock ticks in vote, the four bodies, tail; steps per kind; 19..22: triangle step details
@@ -352,7 +361,12 @@ constexpr unsigned IT_END = 0xFFFFFFFFu; // "the stack is empty": the traversal 
 // A node-kind item no node can have: "the next stack levels are in HBM".  The step that runs it fetches
 // them together with the other lanes' node records instead of making the popping step wait for HBM.
 constexpr unsigned IT_REFILL = 0x1FFFFFFFu;
-constexpr int REFILL = LDS_STACK >= 8 ? 4 : LDS_STACK >= 4 ? 2 : 1; // levels fetched at once
+// levels fetched at once by a refill step
+#ifdef RT_REFILL
+constexpr int refill_levels(int) { return RT_REFILL; }
+#else
+constexpr int refill_levels(int ring) { return ring >= 8 ? 4 : ring >= 4 ? 3 : 1; }
+#endif
 enum { K_NODE = 0, K_CULL = 1, K_TRI = 2, K_SHADE = 3, K_DONE = 4 };
 enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, ST_ITERS, ST_LANES };
 // Words of a ray slot's state kept in HBM (8 bytes each, [word][slot] so lanes coalesce): what
@@ -407,7 +421,8 @@ __device__ __forceinline__ float half_up_get(unsigned short h) { return __uint_a
 __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30f), 1e30f); }
 
 // SPH = true: the scene has a sphere hierarchy (a second instance, so that scenes without one do not pay for it).
-template <bool TRACE, bool SPH>
+// SLOTS, LDS_STACK: see KernelCfg.
+template <bool TRACE, bool SPH, int SLOTS, int LDS_STACK>
 __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCamera cam, rt_params P, const DevTile *tiles, int n_tiles,
                                                              unsigned n_work, unsigned *counter, double *rgb, int *prim,
                                                              const double *rays, int *tri_id, double *tri_t, int *sph_id,
@@ -424,7 +439,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     // array and grow towards each other (a slot is in at most one of them): node up from 0 and cull down from
     // SLOTS - 1, tri up from SLOTS and shade down from 2 * SLOTS - 1
     __shared__ uint2 sQ[2 * SLOTS];
-    static_assert(SLOTS <= 256, "a slot index is kept in 8 bits");
+    constexpr int SLOT_STRIDE = slot_stride(SLOTS), REFILL = refill_levels(LDS_STACK);
+    static_assert(SLOTS >= WAVE && SLOTS <= 256, "a slot index is kept in 8 bits");
+    static_assert((LDS_STACK & (LDS_STACK - 1)) == 0 && REFILL >= 1 && REFILL - 1 <= LDS_STACK, "the refilled levels but the first go to the ring");
     static_assert(SLOT_STRIDE % 32 == 0 && SLOT_STRIDE >= SLOTS, "a wavefront's 4-byte columns of the HBM state start on a cache line");
 #ifdef RT_LDS_PAD // occupancy experiments: unused LDS that the compiler cannot drop
     __shared__ unsigned lds_pad[RT_LDS_PAD / 4];
@@ -1227,7 +1244,17 @@ struct rt_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     hipStream_t last_stream = nullptr;
+    bool deep = false;           // which build of the kernel this scene runs (KernelCfg)
+    int slots = 0;               // its slots per workgroup
 };
+
+using KernelFn = void (*)(DevScene, DevCamera, rt_params, const DevTile *, int, unsigned, unsigned *, double *, int *, const double *, int *,
+                          double *, int *, double *, unsigned long long *, double *, unsigned *, const int *);
+template <bool TRACE>
+KernelFn pick_kernel(bool sph, bool deep) {
+    if (deep) return sph ? k_main<TRACE, true, CFG_DEEP.slots, CFG_DEEP.ring> : k_main<TRACE, false, CFG_DEEP.slots, CFG_DEEP.ring>;
+    return sph ? k_main<TRACE, true, CFG_SHALLOW.slots, CFG_SHALLOW.ring> : k_main<TRACE, false, CFG_SHALLOW.slots, CFG_SHALLOW.ring>;
+}
 
 namespace {
 
@@ -1613,9 +1640,9 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     HIP_TRY(hipMemsetAsync(s->d_subcnt, 0, (size_t)off * sizeof(unsigned), stream));
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, 16, stream));
     const DevCamera dc = make_camera(cam);
-    const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + SLOTS - 1) / SLOTS);
+    const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + s->slots - 1) / s->slots);
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    const auto kern = s->d.sph_root ? k_main<false, true> : k_main<false, false>;
+    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, dc, *p, (const DevTile *)s->d_tiles, n_tiles,
                        (unsigned)(blocks * 256), s->d_counter, d_rgb, d_prim, (const double *)nullptr, (int *)nullptr,
                        (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats, s->d_sub, s->d_subcnt, (const int *)s->d_blk_tile);
@@ -1831,14 +1858,20 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (!rc) rc = upload(&s->sshade, ss);
     if (rc) { rt_free_scene(s); return rc; }
 
+    int deep_from = DEEP_TREE;
+    if (const char *e = getenv("RT_HIP_DEEP_TREE")) deep_from = atoi(e); // tuning / test knob: 0 = always the 8-level ring
+    s->deep = D->tree_depth >= deep_from;
+    const KernelCfg cfg = s->deep ? CFG_DEEP : CFG_SHALLOW;
+    s->slots = cfg.slots;
+    const int LDS_STACK = cfg.ring;
     // persistent grid: as many workgroups as the chip holds at this kernel's occupancy
     hipDeviceProp_t pr;
     int per_cu = 0;
     if (hipGetDeviceProperties(&pr, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_main<false, true>), WAVE, 0) != hipSuccess || per_cu < 1)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel<false>(true, s->deep), WAVE, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
     s->grid = pr.multiProcessorCount * per_cu;
-    const int n_slots = s->grid * SLOT_STRIDE;
+    const int n_slots = s->grid * slot_stride(s->slots);
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
     const int need_depth = D->tree_depth + 3 * cull_depth + 5 + (sph_root ? 1 : 0);
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK + 1 : 0; // levels that can move to HBM
@@ -2001,11 +2034,11 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_counter, 0, 16);
     if (e == hipSuccess) {
-        const long long want = (n + SLOTS - 1) / SLOTS;
+        const long long want = (n + s->slots - 1) / s->slots;
         const int grid = (int)std::min<long long>(s->grid, want); // stay within the slot count the state arrays were sized for
         rt_params none = {1, 0, 0, 0, 1, 0, 0};
         DevCamera nocam = {};
-        const auto kern = s->d.sph_root ? k_main<true, true> : k_main<true, false>;
+        const KernelFn kern = pick_kernel<true>(s->d.sph_root != 0, s->deep);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, nullptr, s->d, nocam, none, (const DevTile *)nullptr, 0,
                            (unsigned)n, s->d_counter, (double *)nullptr, (int *)nullptr, (const double *)d_rays, d_ti, d_tt, d_si,
                            d_st, s->d_stats, (double *)nullptr, (unsigned *)nullptr, (const int *)nullptr);

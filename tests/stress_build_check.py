@@ -1,5 +1,6 @@
 """Run by tests/test_gpu_stress_build.py in a child process whose RT_HIP_LIB points at the stress
-build of the HIP library (2-level stack ring, 3 slots per lane): explicit rays and a small frame
+build of the HIP library (2-level stack ring, 192 slots per wavefront), or whose RT_HIP_DEEP_TREE
+makes the default library run its build for deep trees on these shallow ones: explicit rays and a small frame
 against the CPU oracle, same bars as tests/test_gpu_parity.py.  Prints OK on success."""
 import os
 import sys
@@ -18,7 +19,8 @@ from raytrace_amd import scenes  # noqa: E402
 
 
 def main():
-    assert "stress" in os.environ.get("RT_HIP_LIB", ""), "RT_HIP_LIB must point at the stress build"
+    assert "stress" in os.environ.get("RT_HIP_LIB", "") or "RT_HIP_DEEP_TREE" in os.environ, \
+        "RT_HIP_LIB must point at the stress build, or RT_HIP_DEEP_TREE select the other kernel build"
     po.build()
     for sc, ctr, spr, n in ((scenes.sponza_class(40000, detail=0.3), np.array([50, 40, 130.0]), 60.0, 5000),
                             (scenes.bunny_class(5000), np.array([50, 40, 80.0]), 60.0, 8000)):
