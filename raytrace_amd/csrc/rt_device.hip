@@ -382,18 +382,18 @@ enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13
        LS_ST = 20, LS_SI = 21, LS_PEND = 22 };
 constexpr int PEND_WORDS = 10;
 constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
-// per-slot flags word in LDS: stack depth (bits 0-7), the frame's "has a hit" flag (8), the kind
-// of step the slot waits for (9-11), number of stack levels that live in HBM only (12-19)
+// per-slot flags word in LDS: stack depth (bits 0-7), the frame's "has a hit" flag (8), the frame's
+// number of far children that are only counted (9-11), number of stack levels that live in HBM only (12-19)
 constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u;
 constexpr int ST_LO = 12;
 // Far children that are only counted (their box is certainly missed) when the near subtree returns false need no
-// stack entry if nothing else waits for that return: the frame keeps their number in two bits of its flags word,
-// an after item or marker saves the enclosing frame's number in bits 26-27, and whatever ends the frame (such an
+// stack entry if nothing else waits for that return: the frame keeps their number (up to seven) in three bits of its flags word,
+// an after item or marker saves the enclosing frame's number in bits 25-27, and whatever ends the frame (such an
 // item coming off the stack, or the end of the traversal) adds the number to the visits if the frame found nothing.
-constexpr unsigned ST_N = 0x600u;
-constexpr int ST_NSH = 9, IT_NSH = 26;
-// (after items and markers carry a node granule / 2 in bits 1-25; bit 0 marks a marker)
-__device__ __forceinline__ unsigned after_granule(unsigned x) { return (x & 0x03FFFFFEu) << 1; }
+constexpr unsigned ST_N = 0xE00u, N_MAX = 7u;
+constexpr int ST_NSH = 9, IT_NSH = 25;
+// (after items and markers carry a node granule / 2 in bits 1-24; bit 0 marks a marker)
+__device__ __forceinline__ unsigned after_granule(unsigned x) { return (x & 0x01FFFFFEu) << 1; }
 
 // The whole path -- camera ray, KdTree::check without recursion, check_node, sphere scan, radiance()
 // as a loop -- is cut into steps of four kinds:
@@ -540,8 +540,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         auto do_marker = [&](unsigned m) __attribute__((always_inline)) -> bool {
             const unsigned fk = (m >> 28) & 3u;
             const bool near_hit = (st & ST_FLAG) != 0; // what the near child's check() returned
-            vis_add += near_hit ? 0u : ((st >> ST_NSH) & 3u) + (fk == 3u ? 1u : 0u);
-            st = (st & ~ST_N) | (((m >> IT_NSH) & 3u) << ST_NSH);
+            vis_add += near_hit ? 0u : ((st >> ST_NSH) & N_MAX) + (fk == 3u ? 1u : 0u);
+            st = (st & ~ST_N) | (((m >> IT_NSH) & N_MAX) << ST_NSH);
             if ((m >> 30) & 1u) st |= ST_FLAG;          // back in the enclosing frame
             if (!near_hit && (fk == 1u || fk == 2u)) { next = after_granule(m); return false; } // kdtree.cpp:124,133
             return true;
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     // the own list and the far child come after the near subtree; the frame's flag
                     // travels in the item and the near subtree starts with a clean one
                     const unsigned st0 = st;
-                    const unsigned pend = (st >> ST_NSH) & 3u; // counted-only far children of the frame so far
+                    const unsigned pend = (st >> ST_NSH) & N_MAX; // counted-only far children of the frame so far
                     const unsigned after = IT_AFTER | (((st >> 8) & 1u) << 30) | (farkind << 28) | (pend << IT_NSH) | (node >> 1);
                     const unsigned far_item = farkind == 1 ? node + 4 : right;
                     // (written as selects: three cases)
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const bool has_near = near != 0, far12 = farkind == 1 || farkind == 2;
                     const unsigned marker = IT_AFTER | (((st0 >> 8) & 1u) << 30) | (farkind << 28) | (pend << IT_NSH) | (far12 ? far_item >> 1 : 0u) | 1u;
                     // (a far child that is only counted joins the frame's number instead, while that has room)
-                    const bool count_only = farkind == 3 && (st0 & ST_FLAG) == 0 && pend < 3u;
+                    const bool count_only = farkind == 3 && (st0 & ST_FLAG) == 0 && pend < N_MAX;
                     const bool want_marker = (farkind != 0 || (st0 & ST_FLAG) != 0) && !count_only;
                     if (!list_missed || has_near) st &= ~ST_FLAG;
                     if (has_near && list_missed && count_only) st += 1u << ST_NSH;
@@ -730,8 +730,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const unsigned node = after_granule(cur), farkind = (cur >> 28) & 3;
                     const bool near_hit = (st & ST_FLAG) != 0;         // what the near child's check() returned
                     // the far child's check() fails at its box: a visit, nothing else; likewise those the frame kept count of
-                    vis_add += near_hit ? 0u : ((st >> ST_NSH) & 3u) + (farkind == 3 ? 1u : 0u);
-                    st = (st & ~ST_N) | (((cur >> IT_NSH) & 3u) << ST_NSH);
+                    vis_add += near_hit ? 0u : ((st >> ST_NSH) & N_MAX) + (farkind == 3 ? 1u : 0u);
+                    st = (st & ~ST_N) | (((cur >> IT_NSH) & N_MAX) << ST_NSH);
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
                     if (farkind == 3) {}
                     else if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list
@@ -1146,8 +1146,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             if (is_marker(next)) { // (without inner branches: the level below is read whether or not it is taken)
                 const unsigned m = next, fk = (m >> 28) & 3u;
                 const bool near_hit = (st & ST_FLAG) != 0, take_far = !near_hit && (fk == 1u || fk == 2u);
-                vis_add += near_hit ? 0u : ((st >> ST_NSH) & 3u) + (fk == 3u ? 1u : 0u);
-                st = (st & ~ST_N) | (((m >> IT_NSH) & 3u) << ST_NSH);
+                vis_add += near_hit ? 0u : ((st >> ST_NSH) & N_MAX) + (fk == 3u ? 1u : 0u);
+                st = (st & ~ST_N) | (((m >> IT_NSH) & N_MAX) << ST_NSH);
                 st |= ((m >> 30) & 1u) << 8; // ST_FLAG: back in the enclosing frame
                 const unsigned e = stk[(sp - 1) & (LDS_STACK - 1)][slot];
                 const bool in_ring = sp > slo;
@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 sp -= (!take_far && in_ring) ? 1 : 0;
             }
             if (next == IT_END) { // the root's frame ends with the traversal
-                vis_add += (st & ST_FLAG) ? 0u : (st >> ST_NSH) & 3u;
+                vis_add += (st & ST_FLAG) ? 0u : (st >> ST_NSH) & N_MAX;
                 st &= ~ST_N;
             }
         }
@@ -1793,7 +1793,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     const size_t n_cull = cull.size();
     const size_t g_end = g_cull + 4 * n_cull + 4;
     if (g_end > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
-    if ((size_t)D->n_nodes * 4 > ((size_t)1 << 27)) return fail(RT_E_LIMIT, "too many tree nodes for the 25-bit node field of a stack item");
+    if ((size_t)D->n_nodes * 4 > ((size_t)1 << 26)) return fail(RT_E_LIMIT, "too many tree nodes for the 24-bit node field of a stack item");
     pool.resize(g_end * 16, 0);
     if (n_cull) memcpy(&pool[g_cull * 16], cull.data(), n_cull * sizeof(QuadRec));
     std::vector<unsigned char> last((size_t)D->n_list, 0); // device position is the last of its own list
