@@ -464,11 +464,6 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     // (volatile: one lane writes what the others read; the compiler must not keep a lane's old value)
     __shared__ volatile unsigned sStash[2];
     if (lane == 0) { sStash[0] = 0u; sStash[1] = 0u; }
-    // the run of pieces this wavefront takes work from, and how many runs it has not seen used up yet
-    constexpr unsigned N_PARTS = TRACE ? 1u : 8u;
-    const unsigned part_len = TRACE ? n_work : (((n_work >> 8) + N_PARTS - 1) / N_PARTS) << 8; // whole 8x8 blocks
-    unsigned part = TRACE ? 0u : blockIdx.x % N_PARTS; // (reading the XCD's number from the hardware register instead: no difference)
-    int parts_left = (int)N_PARTS;
     // work counters: wavefront-uniform 32-bit sums of lane counts in scalar registers, flushed to
     // the 64-bit totals in HBM long before they can overflow; only the own-list lengths need a
     // per-lane sum
@@ -1050,36 +1045,24 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 // ---- slots without work take the next pixel (or ray) from the shared counter
                 // (render: in whole pixels, i.e. multiples of four pieces, so that a pixel's sub-pixels stay in this
                 // wavefront; what is left over waits in [stash_base, stash_base + stash_n) for the next slots)
-                // The pieces of a frame are split into N_PARTS runs of whole blocks with a counter each; a wavefront
-                // starts with the run of its XCD (workgroups go to the XCDs in turn), so that an XCD's L2 sees the rays
-                // of one band of the image, and moves on to the next run when one is used up.
                 for (;;) {
                     const unsigned long long want = __ballot(need_work);
                     if (want == 0) break;
                     const unsigned k = (unsigned)__popcll(want);
                     const unsigned was_base = sStash[0], was_n = sStash[1];
                     const unsigned take = k <= was_n ? 0u : TRACE ? k : ((k - was_n + 15u) & ~15u); // (sixteen at a time: fewer trips to the counter)
-                    const unsigned part_first = part * part_len;
-                    const unsigned part_n = part_first >= n_work ? 0u : n_work - part_first < part_len ? n_work - part_first : part_len;
-                    unsigned off = 0;
+                    unsigned base = 0;
                     const int leader = __ffsll((long long)want) - 1;
-                    if (take != 0 && lane == leader) off = atomicAdd(counter + part, take);
-                    off = __shfl(off, leader, 64);
-                    const unsigned avail = take == 0 || off >= part_n ? 0u : part_n - off < take ? part_n - off : take;
-                    const unsigned base = part_first + off;
-                    const unsigned used = k <= was_n ? 0u : k - was_n < avail ? k - was_n : avail;
+                    if (take != 0 && lane == leader) base = atomicAdd(counter, take);
+                    base = __shfl(base, leader, 64);
                     if (lane == leader) {
-                        if (k > was_n) { sStash[0] = base + used; sStash[1] = avail - used; }
+                        if (k >= was_n) { sStash[0] = base + (k - was_n); sStash[1] = take - (k - was_n); }
                         else { sStash[0] = was_base + k; sStash[1] = was_n - k; }
                     }
-                    const bool part_empty = take != 0 && avail < take; // this run is used up
-                    if (part_empty) { part = part + 1 == N_PARTS ? 0u : part + 1; parts_left--; }
                     if (need_work) {
                         const unsigned r = (unsigned)__popcll(want & lane_lt);
-                        const bool got = r < was_n + avail;
                         const unsigned w = r < was_n ? was_base + r : base + (r - was_n);
-                        if (!got) { if (parts_left <= 0) { need_work = false; done = true; } } // else: asks the next run
-                        else if (w >= n_work) { need_work = false; done = true; }
+                        if (w >= n_work) { need_work = false; done = true; }
                         else if (TRACE) { outk = w; need_work = false; go_on = true; ro = ld3(rays + 6 * (size_t)w); rd = ld3(rays + 6 * (size_t)w + 3); }
                         else {
                             const unsigned blk = w >> 8, li = (w >> 2) & 63; // a block of 8 x 8 pixels is 256 pieces: pixel, sub-pixel
@@ -1247,7 +1230,7 @@ struct rt_scene {
     void *ovf = nullptr, *lstate = nullptr, *lhdr = nullptr;
     int tree_depth = 0;
     int grid = 0;               // persistent workgroups
-    unsigned *d_counter = nullptr; // piece counters, one per run of the frame's pieces (up to 8)
+    unsigned *d_counter = nullptr; // [0] block counter
     unsigned long long *d_stats = nullptr;
     int *d_blk_tile = nullptr; // tile of every 8x8 block of the current tile list
     long long blk_cap = 0;
@@ -1655,7 +1638,7 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         s->sub_cap = (size_t)off;
     }
     HIP_TRY(hipMemsetAsync(s->d_subcnt, 0, (size_t)off * sizeof(unsigned), stream));
-    HIP_TRY(hipMemsetAsync(s->d_counter, 0, 64, stream));
+    HIP_TRY(hipMemsetAsync(s->d_counter, 0, 16, stream));
     const DevCamera dc = make_camera(cam);
     const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + s->slots - 1) / s->slots);
     HIP_TRY(hipEventRecord(s->ev0, stream));
@@ -1903,7 +1886,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     hipError_t e = hipSuccess;
     if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_slots * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&s->lstate, (size_t)LS_WORDS * n_slots * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_counter, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_counter, 16);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&s->ev0);
@@ -2049,7 +2032,7 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) e = hipMalloc((void **)&d_si, (size_t)n * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(s->d_counter, 0, 64);
+    if (e == hipSuccess) e = hipMemset(s->d_counter, 0, 16);
     if (e == hipSuccess) {
         const long long want = (n + s->slots - 1) / s->slots;
         const int grid = (int)std::min<long long>(s->grid, want); // stay within the slot count the state arrays were sized for

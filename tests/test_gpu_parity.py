@@ -212,6 +212,40 @@ def test_tiles_and_ragged_edges_are_invariant(ra, po, world):
     assert np.array_equal(rgb, full[7:18, 13:32]) and np.array_equal(pid, fpid[7:18, 13:32])
 
 
+def test_large_frame_same_pixels_and_work_for_any_tiling(ra, world):
+    """A frame with many more pieces of work than the chip has ray slots, so that every wavefront
+    takes work many times and runs through all of the frame's piece counters: two different
+    tilings and a repeat give bit-identical pixels, ids and work counters, and every pixel of a
+    lattice matches its own one-pixel launch."""
+    import torch
+    from raytrace_amd import frame
+    w = world["sponza40k"]
+    sizex, sizey = 1000, 1500  # 6 M sub-pixels; not multiples of the tile sizes
+    kw = dict(samps=1, rr_depth=3, rr_mode=0, split_depth=2, hard_depth=64, jitter=1, seed=21)
+    cam, prm = _cam(ra, w["scene"], sizex, sizey), ra.capi.make_params(**kw)
+    w["dev"].stats()
+    results = []
+    for tx, ty in ((64, 64), (96, 200), (64, 64)):
+        tiles = frame.plan_tiles(sizex, sizey, tx, ty)
+        n = frame.tile_pixels(tiles)
+        buf = torch.zeros((n, 3), dtype=torch.float64, device="cuda:0")
+        ids = torch.zeros((n,), dtype=torch.int32, device="cuda:0")
+        w["dev"].render_tiles_device(cam, prm, tiles, buf.data_ptr(), ids.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st = w["dev"].stats()
+        img = frame.assemble_host(sizex, sizey, [tiles], [buf.cpu().numpy()])
+        pid = frame.assemble_host(sizex, sizey, [tiles], [ids.cpu().numpy()], channels=0, dtype=np.int32)
+        results.append((img, pid, {k: st[k] for k in ("rays", "node_visits", "tri_tests", "tri_shades")}))
+    for img, pid, st in results[1:]:
+        assert np.array_equal(img, results[0][0]) and np.array_equal(pid, results[0][1])
+        assert st == results[0][2]
+    assert results[0][2]["rays"] >= 4 * sizex * sizey
+    for x in range(3, sizex, 331):
+        for y in range(5, sizey, 373):
+            rgb, one, _ = w["dev"].render_tile(cam, prm, x, y, 1, 1)
+            assert np.array_equal(rgb[0, 0], results[0][0][x, y]) and one[0, 0] == results[0][1][x, y]
+
+
 def test_frame_renderer_single_rank(ra, world):
     import torch
     from raytrace_amd import frame
