@@ -383,8 +383,9 @@ enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13
 constexpr int PEND_WORDS = 10;
 constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
 // per-slot flags word in LDS: stack depth (bits 0-7), the frame's "has a hit" flag (8), the frame's
-// number of far children that are only counted (9-11), number of stack levels that live in HBM only (12-19)
-constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u;
+// number of far children that are only counted (9-11), number of stack levels that live in HBM only (12-19), "the ray
+// starts far outside the scene" (20)
+constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u, ST_FAR = 1u << 20; // (ST_FAR: see sG)
 constexpr int ST_LO = 12;
 // Far children that are only counted (their box is certainly missed) when the near subtree returns false need no
 // stack entry if nothing else waits for that return: the frame keeps their number (up to seven) in three bits of its flags word,
@@ -418,6 +419,9 @@ __device__ __forceinline__ unsigned after_granule(unsigned x) { return (x & 0x01
 // a float kept in 16 bits: sign, exponent and the top 7 mantissa bits, the magnitude rounded up
 __device__ __forceinline__ unsigned short half_up_put(float x) { return (unsigned short)((__float_as_uint(x) + 0xFFFFu) >> 16); }
 __device__ __forceinline__ float half_up_get(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// a float >= 0 kept in 8 bits: the next power of two (the margins it is used for are far below the boxes' sizes)
+__device__ __forceinline__ unsigned char exp_up_put(float x) { return (unsigned char)((__float_as_uint(x) + 0x7FFFFFu) >> 23); }
+__device__ __forceinline__ float exp_up_get(unsigned char e) { return __uint_as_float((unsigned)e << 23); }
 __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30f), 1e30f); }
 
 // SPH = true: the scene has a sphere hierarchy (a second instance, so that scenes without one do not pay for it).
@@ -432,8 +436,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     __shared__ double2 sB[SLOTS]; // origin z, 1/direction x
     __shared__ double2 sC[SLOTS]; // 1/direction y, z
     // (both kept as the upper half of a float with the magnitude rounded up: a larger margin only culls less)
-    __shared__ unsigned short sM[SLOTS]; // inflation of the current list's culling boxes
-    __shared__ unsigned short sG[SLOTS]; // the ray's margin factor
+    __shared__ unsigned char sM[SLOTS]; // inflation of the current list's culling boxes
+    __shared__ unsigned char sG[SLOTS]; // the ray's margin factor (ST_FAR in the flags word: beyond what the working coefficients cover)
+    __shared__ unsigned short sT[SLOTS]; // the best distance so far (triangles; the same 16-bit form, so never too small)
     __shared__ unsigned stk[LDS_STACK][SLOTS];
     // the slots that wait for a step, one stack per kind: slot | flags word << 8; item.  Two stacks share an
     // array and grow towards each other (a slot is in at most one of them): node up from 0 and cull down from
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 const uint4 *kp = (const uint4 *)(S.pool + (size_t)(2u * S.g_list + 3u * (cur >> 2)) * 16); // boxes of the children and the own list
                 const uint4 k0 = kp[0], k1 = kp[1], k2 = kp[2];
-                const float gfac = half_up_get(sG[slot]);
+                const float gfac = exp_up_get(sG[slot]);
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
                 const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
                 const double mi[3] = {q0.x, q0.y, q1.x}, ma[3] = {q1.y, q2.x, q2.y};
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                         const unsigned kq[5] = {k1.y, k1.z, k1.w, k2.x, k2.y}; // 18 plane bytes: [box][axis][lower, upper]
                         const unsigned kflags = k1.x >> 16;
                         // the list's inflation, as the step that starts the list would compute it
-                        const float mgl = ldexpf(__uint_as_float(k2.z), gfac < 0.0f ? (int)(k2.z & 0xFFu) : 0) * fabsf(gfac);
+                        const float mgl = ldexpf(__uint_as_float(k2.z), (st & ST_FAR) ? (int)(k2.z & 0xFFu) : 0) * gfac;
                         // one inflation for all three boxes, the larger of the two (a larger one only skips less)
                         const float mt = (fmaxf((float)(pad * 1.000001), mgl) + msl) * 1.000001f;
                         f2 ka[3], kb[3];
@@ -717,13 +722,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 uint2 hdr = make_uint2(0u, 0u);
                 if (cur & IT_AFTER) hdr = *(const uint2 *)(S.lhdr + (after_granule(cur) >> 2)); // right child, list header
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
-                float mg = half_up_get(sM[slot]);
+                float mg = exp_up_get(sM[slot]);
                 // (for an after item the flag of the enclosing frame is restored below: st or the item's bit)
                 // (the sphere hierarchy keeps only the nearest sphere: its boxes are always limited by that distance)
                 const bool sph_boxes = SPH && !(cur & IT_AFTER) && (cur & IDX28) >= S.g_sphc;
                 const bool lim_on = sph_boxes || ((st & ST_FLAG) != 0) || ((cur & IT_AFTER) && ((cur >> 30) & 1));
-                double best_lim = 0.0;
-                if (lim_on) best_lim = ls[(sph_boxes ? LS_ST : LS_BT) * lss];
+                float best_lim = half_up_get(sT[slot]);
+                if (sph_boxes) best_lim = (float)ls[LS_ST * lss];
                 boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
                     const unsigned right = hdr.x, meta = hdr.y;
@@ -740,10 +745,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                         if ((meta & 0xFF) == 0) want_pop = true;
                         else next = it.x;
                     } else { // inflation of this list's boxes, see ray_margin_factor(); a larger one only culls less
-                        const float gfac = half_up_get(sG[slot]); // negative for a ray from far outside the scene: the larger coefficient
+                        const float gfac = exp_up_get(sG[slot]);
                         // (the exponent in the low mantissa bits only makes the coefficient a little larger)
-                        mg = ldexpf(__uint_as_float(meta), gfac < 0.0f ? (int)(meta & 0xFFu) : 0) * fabsf(gfac);
-                        { const unsigned short h = half_up_put(mg); sM[slot] = h; mg = half_up_get(h); }
+                        mg = ldexpf(__uint_as_float(meta), (st & ST_FAR) ? (int)(meta & 0xFFu) : 0) * gfac;
+                        { const unsigned char h = exp_up_put(mg); sM[slot] = h; mg = exp_up_get(h); }
                     }
                 }
                 if (SPH && !(cur & IT_AFTER) && (cur & IT_CHAIN)) { // root of the sphere hierarchy: the kd-tree is done
@@ -753,7 +758,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const double gs = fabs(a.x - S.sph_cen[0]) + fabs(a.y - S.sph_cen[1]) + fabs(b.x - S.sph_cen[2]) + S.sph_h;
                     const float gsf = (float)gs * 1.000001f;
                     mg = S.sph_k * gsf * gsf + S.sph_c;
-                    { const unsigned short h = half_up_put(mg); sM[slot] = h; mg = half_up_get(h); }
+                    { const unsigned char h = exp_up_put(mg); sM[slot] = h; mg = exp_up_get(h); }
                 }
                 if (boxes) {
                     // Slab test of the four inflated boxes in single precision, two planes per packed
@@ -788,7 +793,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     // Once the frame has a hit (its check() returns true whatever follows, kdtree.cpp:105-107), a
                     // triangle can only matter by being nearer than the best one: boxes that the ray enters
                     // beyond that distance are dropped.  (Equal distances stay: the parameters err towards "met".)
-                    const float tlim = lim_on ? (float)best_lim * 1.000001f : INFINITY;
+                    const float tlim = lim_on ? best_lim * 1.000001f : INFINITY;
                     bool hit[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -877,6 +882,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     }
                     if (better) {
                         ls[LS_BT * lss] = t;
+                        sT[slot] = half_up_put((float)t * 1.000001f); // (t > 0; the factor covers the rounding to single)
                         ls[LS_HA * lss] = __longlong_as_double((long long)(unsigned long long)((unsigned)w9 & ~TRI_LAST));
                     }
                     if (t < 1e10) st |= ST_FLAG;
@@ -1116,10 +1122,11 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     sC[slot] = make_double2(iy, iz);
                     ls[LS_V * lss] = rd.x; ls[(LS_V + 1) * lss] = rd.y; ls[(LS_V + 2) * lss] = rd.z;
                     ls[LS_BT * lss] = 1e20;
+                    sT[slot] = 0x7F80u; // infinity
                     ls[LS_HA * lss] = __longlong_as_double(-1ll);                   // no triangle
-                    // negative: beyond the factor (4 * reach + 1 at upload) that the lists' working coefficients cover
-                    sG[slot] = half_up_put(gf <= (float)(3.9 * S.reach) ? gf : -gf);
-                    st = 0;
+                    sG[slot] = exp_up_put(gf);
+                    // beyond the factor (4 * reach + 1 at upload) that the lists' working coefficients cover: the larger ones
+                    st = gf <= (float)(3.9 * S.reach) ? 0u : ST_FAR;
                     sp = 0; slo = 0;
                     if (SPH) { // many spheres: their hierarchy is searched after the kd-tree, from the bottom of the stack
                         const bool unit = fabs(dot(rd, rd) - 1.0) <= 1e-12; // what the boxes' inflation assumes
@@ -1168,7 +1175,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             const int below = nk == K_NODE ? q0 : nk == K_CULL ? q1 : nk == K_TRI ? q2 : q3;
             const int at = below + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
             if (nk != K_DONE)
-                sQ[qindex((int)nk, at)] = make_uint2((unsigned)slot | (((st & (ST_FLAG | ST_N)) | (unsigned)sp | ((unsigned)slo << ST_LO)) << 8), next == IT_END ? 0u : next);
+                sQ[qindex((int)nk, at)] = make_uint2((unsigned)slot | (((st & (ST_FLAG | ST_N | ST_FAR)) | (unsigned)sp | ((unsigned)slo << ST_LO)) << 8), next == IT_END ? 0u : next);
             q0 += __popcll(m0); q1 += __popcll(m1); q2 += __popcll(m2); q3 += __popcll(m3);
         }
 #ifdef RT_PROFILE
