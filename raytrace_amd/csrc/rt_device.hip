@@ -391,7 +391,11 @@ constexpr int ST_LO = 12;
 // stack entry if nothing else waits for that return: the frame keeps their number (up to seven) in three bits of its flags word,
 // an after item or marker saves the enclosing frame's number in bits 25-27, and whatever ends the frame (such an
 // item coming off the stack, or the end of the traversal) adds the number to the visits if the frame found nothing.
-constexpr unsigned ST_N = 0xE00u, N_MAX = 7u;
+#ifndef RT_NMAX
+#define RT_NMAX 7 // (a test build uses 1, so that the marker a frame needs beyond that is used often)
+#endif
+constexpr unsigned ST_N = 0xE00u, N_MAX = RT_NMAX;
+static_assert(N_MAX >= 1 && N_MAX <= 7, "three bits");
 constexpr int ST_NSH = 9, IT_NSH = 25;
 // (after items and markers carry a node granule / 2 in bits 1-24; bit 0 marks a marker)
 __device__ __forceinline__ unsigned after_granule(unsigned x) { return (x & 0x01FFFFFEu) << 1; }
@@ -545,8 +549,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         auto do_marker = [&](unsigned m) __attribute__((always_inline)) -> bool {
             const unsigned fk = (m >> 28) & 3u;
             const bool near_hit = (st & ST_FLAG) != 0; // what the near child's check() returned
-            vis_add += near_hit ? 0u : ((st >> ST_NSH) & N_MAX) + (fk == 3u ? 1u : 0u);
-            st = (st & ~ST_N) | (((m >> IT_NSH) & N_MAX) << ST_NSH);
+            vis_add += near_hit ? 0u : ((st >> ST_NSH) & 7u) + (fk == 3u ? 1u : 0u);
+            st = (st & ~ST_N) | (((m >> IT_NSH) & 7u) << ST_NSH);
             if ((m >> 30) & 1u) st |= ST_FLAG;          // back in the enclosing frame
             if (!near_hit && (fk == 1u || fk == 2u)) { next = after_granule(m); return false; } // kdtree.cpp:124,133
             return true;
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     // the own list and the far child come after the near subtree; the frame's flag
                     // travels in the item and the near subtree starts with a clean one
                     const unsigned st0 = st;
-                    const unsigned pend = (st >> ST_NSH) & N_MAX; // counted-only far children of the frame so far
+                    const unsigned pend = (st >> ST_NSH) & 7u; // counted-only far children of the frame so far
                     const unsigned after = IT_AFTER | (((st >> 8) & 1u) << 30) | (farkind << 28) | (pend << IT_NSH) | (node >> 1);
                     const unsigned far_item = farkind == 1 ? node + 4 : right;
                     // (written as selects: three cases)
@@ -735,8 +739,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const unsigned node = after_granule(cur), farkind = (cur >> 28) & 3;
                     const bool near_hit = (st & ST_FLAG) != 0;         // what the near child's check() returned
                     // the far child's check() fails at its box: a visit, nothing else; likewise those the frame kept count of
-                    vis_add += near_hit ? 0u : ((st >> ST_NSH) & N_MAX) + (farkind == 3 ? 1u : 0u);
-                    st = (st & ~ST_N) | (((cur >> IT_NSH) & N_MAX) << ST_NSH);
+                    vis_add += near_hit ? 0u : ((st >> ST_NSH) & 7u) + (farkind == 3 ? 1u : 0u);
+                    st = (st & ~ST_N) | (((cur >> IT_NSH) & 7u) << ST_NSH);
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
                     if (farkind == 3) {}
                     else if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list
@@ -1153,8 +1157,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             if (is_marker(next)) { // (without inner branches: the level below is read whether or not it is taken)
                 const unsigned m = next, fk = (m >> 28) & 3u;
                 const bool near_hit = (st & ST_FLAG) != 0, take_far = !near_hit && (fk == 1u || fk == 2u);
-                vis_add += near_hit ? 0u : ((st >> ST_NSH) & N_MAX) + (fk == 3u ? 1u : 0u);
-                st = (st & ~ST_N) | (((m >> IT_NSH) & N_MAX) << ST_NSH);
+                vis_add += near_hit ? 0u : ((st >> ST_NSH) & 7u) + (fk == 3u ? 1u : 0u);
+                st = (st & ~ST_N) | (((m >> IT_NSH) & 7u) << ST_NSH);
                 st |= ((m >> 30) & 1u) << 8; // ST_FLAG: back in the enclosing frame
                 const unsigned e = stk[(sp - 1) & (LDS_STACK - 1)][slot];
                 const bool in_ring = sp > slo;
@@ -1162,7 +1166,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 sp -= (!take_far && in_ring) ? 1 : 0;
             }
             if (next == IT_END) { // the root's frame ends with the traversal
-                vis_add += (st & ST_FLAG) ? 0u : (st >> ST_NSH) & N_MAX;
+                vis_add += (st & ST_FLAG) ? 0u : (st >> ST_NSH) & 7u;
                 st &= ~ST_N;
             }
         }
