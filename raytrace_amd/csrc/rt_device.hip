@@ -723,8 +723,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 const unsigned g = (cur & IT_AFTER) ? S.g_list + after_granule(cur) : (cur & IDX28);
                 const uint4 *p = (const uint4 *)(S.pool + (size_t)g * 16);
                 const uint4 r0 = p[0], r1 = p[1], r2 = p[2], it = p[3];
-                uint2 hdr = make_uint2(0u, 0u);
-                if (cur & IT_AFTER) hdr = *(const uint2 *)(S.lhdr + (after_granule(cur) >> 2)); // right child, list header
+                // right child, list header (every lane loads, the others node 0's: a load under a branch of its own
+                // makes the compiler wait for all of the loads above before it goes on)
+                const uint2 hdr = *(const uint2 *)(S.lhdr + ((cur & IT_AFTER) ? after_granule(cur) >> 2 : 0u));
                 const double2 a = sA[slot], b = sB[slot], c = sC[slot];
                 float mg = exp_up_get(sM[slot]);
                 // (for an after item the flag of the enclosing frame is restored below: st or the item's bit)
