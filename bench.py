@@ -170,6 +170,10 @@ def main():
         ref_bytes = (per_launch["node_visits"] * B_NODE + per_launch["tri_tests"] * B_TRI + per_launch["tri_shades"] * B_SHADE
                      + per_launch["sph_tests"] * B_SPH)
         avg_ms = float(np.mean(kern_ms))
+        # the render kernel instance the library picks at upload: sphere hierarchy or not; 140 slots with an
+        # 8-level stack ring for trees of 28 levels and more, else 152 with a 4-level ring
+        deep = int(host.desc.contents.tree_depth) >= int(os.environ.get("RT_HIP_DEEP_TREE", "28"))
+        kernel_name = "k_main<false, %s, %s>" % ("true" if host.num_spheres >= 16 else "false", "140, 8" if deep else "152, 4")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s (node), Sponza-class 4K depth-5" if args.workload == "sponza" else f"Mrays/s (node), {args.workload}",
@@ -182,7 +186,7 @@ def main():
                        "parallelism": f"tiles%{world} + gather", "rays_per_frame": rays_total / args.steps},
             "frame_time_ms": elapsed / args.steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_main<false, false, 152, 4>", "kernel_ms_avg": avg_ms,
+                         "traffic": None, "kernel": kernel_name, "kernel_ms_avg": avg_ms,
                          "per_ray": {"node_visits": per_launch["node_visits"] / max(1, per_launch["rays"]),
                                      "tri_tests_reference": per_launch["tri_tests"] / max(1, per_launch["rays"]),
                                      "tri_tests_done": per_launch["tri_tests_done"] / max(1, per_launch["rays"]),
