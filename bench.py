@@ -175,6 +175,15 @@ def main():
         deep = int(host.desc.contents.tree_depth) >= int(os.environ.get("RT_HIP_DEEP_TREE", "28"))
         kernel_name = "k_main<false, %s, %s>" % ("true" if host.num_spheres >= 16 else "false", "140, 8" if deep else "152, 4")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from hardware counters cannot be collected inside this process; the figure of the
+        # last profiled full-size launch of the same workload is kept in bench_traffic.json (how: its "source")
+        traffic, traffic_source = None, None
+        tf = os.path.join(ROOT, "bench_traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as fh:
+                tj = json.load(fh)
+            if (tj["workload"], tj["sizex_rows"], tj["sizey_cols"], tj["samps_per_subpixel"]) == (args.workload, sizex, sizey, args.samps) and world == 1:
+                traffic, traffic_source = tj["traffic_bytes_per_launch"], tj["source"]
         out = {
             "metric": "Mrays/s (node), Sponza-class 4K depth-5" if args.workload == "sponza" else f"Mrays/s (node), {args.workload}",
             "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -186,7 +195,7 @@ def main():
                        "parallelism": f"tiles%{world} + gather", "rays_per_frame": rays_total / args.steps},
             "frame_time_ms": elapsed / args.steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": kernel_name, "kernel_ms_avg": avg_ms,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms_avg": avg_ms,
                          "per_ray": {"node_visits": per_launch["node_visits"] / max(1, per_launch["rays"]),
                                      "tri_tests_reference": per_launch["tri_tests"] / max(1, per_launch["rays"]),
                                      "tri_tests_done": per_launch["tri_tests_done"] / max(1, per_launch["rays"]),
