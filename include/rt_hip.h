@@ -120,11 +120,16 @@ typedef struct rt_stats {
     uint64_t tri_shades;  /* rays whose chosen hit is a triangle (raytrace.cpp:58-67) */
     /* what the kernel actually executed (long own lists are culled conservatively, results unchanged) */
     uint64_t tri_tests_done; /* exact triangle tests performed */
-    uint64_t cull_tests;     /* culling records (two boxes each) tested */
+    uint64_t cull_tests;     /* culling records (four boxes each) tested */
     /* the wavefront scheduler: steps executed and lanes that took part in them
      * (sched_lanes / (64 * sched_steps) = fraction of lanes doing useful work per step) */
     uint64_t sched_steps;
     uint64_t sched_lanes;
+    /* records actually fetched: node visits that loaded the node's records (a visit decided in the parent's
+     * step from the child's box loads nothing), and spheres tested one by one (through the sphere hierarchy,
+     * or by the scan when the scene has no hierarchy) */
+    uint64_t node_fetches;
+    uint64_t sph_tests_done;
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* opaque, one per (scene, device) */
@@ -149,7 +154,8 @@ int rt_free_scene(rt_scene *s);
  *               i.e. the value the reference accumulates into col[] (raytrace.cpp:205)
  *   prim_id_out optional [rows*cols]: primitive hit by the pixel's first camera ray
  *               (sub-pixel 0,0, sample 0)
- *   stats       optional
+ *   stats       optional; the scene's work counters are cleared before the launch and after it (what earlier
+ *               rt_render_tiles_device launches accumulated and rt_get_stats has not fetched is discarded)
  */
 int rt_render_tile(rt_scene *s, const rt_camera *cam, const rt_tile *tile, const rt_params *p,
                    double *rgb_out, int32_t *prim_id_out, rt_stats *stats);
@@ -178,6 +184,7 @@ int rt_last_kernel_ms(rt_scene *s, float *ms);
  * at raytrace.cpp:46-47, KdTree::check and sphere_intersect.  Host buffers, synchronous.
  *   tri_id/tri_t  global triangle id or -1, and the distance the query left behind (1e20 on a miss)
  *   sph_id/sph_t  sphere index or -1, and its distance (1e20 on a miss)
+ * Like rt_render_tile it clears the scene's work counters before and after.
  */
 int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, double *tri_t,
                   int32_t *sph_id, double *sph_t, rt_stats *stats);

@@ -46,7 +46,8 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64),
                 ("tri_shades", C.c_uint64), ("tri_tests_done", C.c_uint64), ("cull_tests", C.c_uint64),
-                ("sched_steps", C.c_uint64), ("sched_lanes", C.c_uint64)]
+                ("sched_steps", C.c_uint64), ("sched_lanes", C.c_uint64), ("node_fetches", C.c_uint64),
+                ("sph_tests_done", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

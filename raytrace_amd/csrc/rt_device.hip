@@ -80,9 +80,9 @@ constexpr int DEEP_TREE = 28; // tree depth from which the 8-level ring is used
 constexpr int slot_stride(int slots) { return (slots + 31) & ~31; }
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 #ifdef RT_PROFILE
-constexpr int N_STATS = 23; // 9..18: clock ticks in vote, the four bodies, tail; steps per kind; 19..22: triangle step details
+constexpr int N_STATS = 25; // 11..20: clock ticks in vote, the four bodies, tail; steps per kind; 21..24: triangle step details
 #else
-constexpr int N_STATS = 9;
+constexpr int N_STATS = 11;
 #endif
 #ifndef RT_SMALL_LIST
 #define RT_SMALL_LIST 1
@@ -368,7 +368,7 @@ constexpr int refill_levels(int) { return RT_REFILL; }
 constexpr int refill_levels(int ring) { return ring >= 8 ? 4 : ring >= 4 ? 3 : 1; }
 #endif
 enum { K_NODE = 0, K_CULL = 1, K_TRI = 2, K_SHADE = 3, K_DONE = 4 };
-enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, ST_ITERS, ST_LANES };
+enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, ST_ITERS, ST_LANES, ST_NFETCH, ST_SPHDONE };
 // Words of a ray slot's state kept in HBM (8 bytes each, [word][slot] so lanes coalesce): what
 // only the shading step touches, plus the ray direction (read together with a record).
 //   LS_PST  low: depth (bits 0-19), pending branches (20-22), sub-pixel (23-24), into (25),
@@ -477,6 +477,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     // the 64-bit totals in HBM long before they can overflow; only the own-list lengths need a
     // per-lane sum
     unsigned c_rays = 0, c_visits = 0, c_shades = 0, c_done = 0, c_culls = 0, c_iters = 0, c_lanes = 0;
+    unsigned c_nfetch = 0, c_sphdone = 0, c_scans = 0; // node records fetched; spheres tested one by one; rays that scanned all spheres
     unsigned long long l_tris = 0;
     unsigned l_vis = 0; // visits counted by single lanes (far children that are only counted)
     auto flush = [&]() __attribute__((always_inline)) {
@@ -488,8 +489,11 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             if (c_culls) atomicAdd(gstats + ST_CULLS, (unsigned long long)c_culls);
             atomicAdd(gstats + ST_ITERS, (unsigned long long)c_iters);
             atomicAdd(gstats + ST_LANES, (unsigned long long)c_lanes);
+            if (c_nfetch) atomicAdd(gstats + ST_NFETCH, (unsigned long long)c_nfetch);
+            if (c_sphdone | c_scans) atomicAdd(gstats + ST_SPHDONE, (unsigned long long)c_sphdone + (unsigned long long)c_scans * (unsigned)S.n_sph);
         }
         c_rays = c_visits = c_shades = c_done = c_culls = c_iters = c_lanes = 0;
+        c_nfetch = c_sphdone = c_scans = 0;
     };
 #define RT_SCOUNT(c, n) (c) += (unsigned)(n)
 
@@ -716,7 +720,9 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     if (sp - k >= 0) stk[(sp - k) & (LDS_STACK - 1)][slot] = rf[k];
                 slo = sp - (REFILL - 1) > 0 ? sp - (REFILL - 1) : 0;
             }
-            RT_SCOUNT(c_visits, nrun - (int)__popcll(__ballot(refill | marker)) + (int)__popcll(__ballot(skipped)) + (int)__popcll(__ballot(skipped_far)));
+            const int entered = nrun - (int)__popcll(__ballot(refill | marker)); // lanes that fetched a node's records
+            RT_SCOUNT(c_nfetch, entered);
+            RT_SCOUNT(c_visits, entered + (int)__popcll(__ballot(skipped)) + (int)__popcll(__ballot(skipped_far)));
         } else if (pick == K_CULL) {
             bool boxes = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
@@ -902,9 +908,11 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 p_tri[3] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) == 0 && t > EPS)); // ... that hit
 #endif
             }
-            RT_SCOUNT(c_done, nrun - (int)__popcll(__ballot(is_sph)));
+            const int nsph = (int)__popcll(__ballot(is_sph));
+            RT_SCOUNT(c_done, nrun - nsph);
+            RT_SCOUNT(c_sphdone, nsph);
         } else {
-            bool ev_ray = false, ev_shade = false;
+            bool ev_ray = false, ev_shade = false, ev_scan = false;
             if (run) { // ---- traversal finished (or nothing started yet)
                 bool go_on = false, need_primary = false, need_work = false;
                 d3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
@@ -927,7 +935,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     int ids;
                     const long long wsi = SPH ? __double_as_longlong(ls[LS_SI * lss]) : -2ll;
                     if (wsi != -2ll) { ts = ls[LS_ST * lss]; ids = (int)wsi; } // found through the hierarchy
-                    else trace_spheres(S, o, d, ts, ids);
+                    else { trace_spheres(S, o, d, ts, ids); ev_scan = true; }
                     const bool fo = to < 1e10, fs = ts < 1e10;
                     if (TRACE) {
                         if (fo && !(ts < to)) ev_shade = true;
@@ -1145,6 +1153,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
             }
             RT_SCOUNT(c_rays, (unsigned)__popcll(__ballot(ev_ray)));
             RT_SCOUNT(c_shades, (unsigned)__popcll(__ballot(ev_shade)));
+            RT_SCOUNT(c_scans, (unsigned)__popcll(__ballot(ev_scan)));
             if (c_iters >> 24) flush();
         }
 
@@ -1192,8 +1201,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     }
 #ifdef RT_PROFILE
     if (lane == 0) {
-        atomicAdd(gstats + 9, p_vote); atomicAdd(gstats + 14, p_tail);
-        for (int k = 0; k < 4; k++) { atomicAdd(gstats + 10 + k, p_body[k]); atomicAdd(gstats + 15 + k, p_n[k]); atomicAdd(gstats + 19 + k, p_tri[k]); }
+        atomicAdd(gstats + 11, p_vote); atomicAdd(gstats + 16, p_tail);
+        for (int k = 0; k < 4; k++) { atomicAdd(gstats + 12 + k, p_body[k]); atomicAdd(gstats + 17 + k, p_n[k]); atomicAdd(gstats + 21 + k, p_tri[k]); }
     }
 #endif
 
@@ -1241,7 +1250,7 @@ struct rt_scene {
     void *pool = nullptr, *tshade = nullptr, *tlist = nullptr, *sph = nullptr, *sshade = nullptr;
     void *ovf = nullptr, *lstate = nullptr, *lhdr = nullptr;
     int tree_depth = 0;
-    int grid = 0;               // persistent workgroups
+    int grid = 0, grid_trace = 0; // persistent workgroups of the render / explicit-ray kernel
     unsigned *d_counter = nullptr; // [0] block counter
     unsigned long long *d_stats = nullptr;
     int *d_blk_tile = nullptr; // tile of every 8x8 block of the current tile list
@@ -1254,6 +1263,9 @@ struct rt_scene {
     unsigned *d_subcnt = nullptr; // finished sub-pixels per pixel
     size_t sub_cap = 0;          // pixels both hold
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_tables = nullptr;       // recorded behind the last upload of the tile tables
+    hipStream_t tables_stream = nullptr;  // the stream that upload was queued on
+    bool tables_valid = false;            // d_tiles / d_blk_tile hold what h_tiles / h_blk_tile say
     bool timed = false;
     hipStream_t last_stream = nullptr;
     bool deep = false;           // which build of the kernel this scene runs (KernelCfg)
@@ -1515,7 +1527,7 @@ void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &
     hdr.meta = bits | r;
 }
 
-int validate(const rt_scene_desc *D) {
+int validate(const rt_scene_desc *D, int *real_depth) {
     if (!D) return fail(RT_E_INVALID, "desc is NULL");
     if (D->n_nodes < 1) return fail(RT_E_INVALID, "n_nodes must be >= 1 (got %d)", D->n_nodes);
     if (D->n_nodes > (1 << 25)) return fail(RT_E_LIMIT, "n_nodes %d exceeds %d", D->n_nodes, 1 << 25);
@@ -1540,6 +1552,28 @@ int validate(const rt_scene_desc *D) {
         run += D->node_count[i];
     }
     if (run != D->n_list) return fail(RT_E_INVALID, "own lists cover %lld entries, n_list is %d", run, D->n_list);
+    // Every node but the root has exactly one parent, and the longest root-to-leaf path must not exceed what the
+    // caller states: tree_depth alone sizes the per-slot traversal stacks, which the kernel does not bounds-check.
+    // (Children follow their parent in pre-order, so one forward pass gives every node's level.)
+    {
+        std::vector<int> level((size_t)D->n_nodes, 0);
+        level[0] = 1;
+        int deepest = 1;
+        for (int i = 0; i < D->n_nodes; i++) {
+            if (level[i] == 0) return fail(RT_E_INVALID, "node %d is not reachable from the root", i);
+            const int kids[2] = {D->node_left[i], D->node_right[i]};
+            for (int c = 0; c < 2; c++) {
+                if (kids[c] < 0) continue;
+                if (c == 1 && kids[1] == kids[0]) return fail(RT_E_INVALID, "node %d: both children are node %d", i, kids[c]);
+                if (level[kids[c]] != 0) return fail(RT_E_INVALID, "node %d has more than one parent", kids[c]);
+                level[kids[c]] = level[i] + 1;
+                if (level[kids[c]] > deepest) deepest = level[kids[c]];
+            }
+        }
+        if (D->tree_depth < deepest)
+            return fail(RT_E_INVALID, "tree_depth is %d but the longest root-to-leaf path has %d nodes", D->tree_depth, deepest);
+        if (real_depth) *real_depth = deepest;
+    }
     std::vector<unsigned char> seen((size_t)D->n_tris, 0);
     for (int i = 0; i < D->n_list; i++) {
         const int g = D->list_tri[i];
@@ -1612,7 +1646,8 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         d.blk_cols = (t.cols + 7) / 8;
         off += (long long)t.rows * t.cols;
         blocks += (long long)((t.rows + 7) / 8) * d.blk_cols;
-        if (blocks > 0xFFFFFELL) return fail(RT_E_LIMIT, "too many pixel blocks in one launch");
+        // (the 32-bit work counter also takes the overshoot of every slot that finds the work used up: leave room for it)
+        if (blocks > 0xF00000LL) return fail(RT_E_LIMIT, "too many pixel blocks in one launch");
     }
     HIP_TRY(hipSetDevice(s->dev));
     if (n_tiles > s->tiles_cap) {
@@ -1621,7 +1656,7 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         s->tiles_cap = 0;
         HIP_TRY(hipMalloc((void **)&s->d_tiles, sizeof(DevTile) * (size_t)n_tiles));
         s->tiles_cap = n_tiles;
-        s->h_tiles.clear();
+        s->tables_valid = false;
     }
     if (blocks > s->blk_cap) {
         if (s->d_blk_tile) HIP_TRY(hipFree(s->d_blk_tile));
@@ -1629,9 +1664,10 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         s->blk_cap = 0;
         HIP_TRY(hipMalloc((void **)&s->d_blk_tile, sizeof(int) * (size_t)blocks));
         s->blk_cap = blocks;
-        s->h_tiles.clear();
+        s->tables_valid = false;
     }
-    if (s->h_tiles.size() != ht.size() || memcmp(s->h_tiles.data(), ht.data(), sizeof(DevTile) * ht.size()) != 0) {
+    if (!s->tables_valid || s->h_tiles.size() != ht.size() || memcmp(s->h_tiles.data(), ht.data(), sizeof(DevTile) * ht.size()) != 0) {
+        s->tables_valid = false; // until both copies are queued
         s->h_tiles = ht; // the copies below read members of *s, which stay alive until the next call
         s->h_blk_tile.resize((size_t)blocks);
         for (int i = 0; i < n_tiles; i++) {
@@ -1640,6 +1676,12 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         }
         HIP_TRY(hipMemcpyAsync(s->d_blk_tile, s->h_blk_tile.data(), sizeof(int) * (size_t)blocks, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(s->d_tiles, s->h_tiles.data(), sizeof(DevTile) * ht.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(s->ev_tables, stream));
+        s->tables_stream = stream;
+        s->tables_valid = true;
+    } else if (stream != s->tables_stream) {
+        // the cached tables were uploaded on another stream: this launch must not start before they have landed
+        HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables, 0));
     }
     if ((size_t)off > s->sub_cap) {
         if (s->d_sub) HIP_TRY(hipFree(s->d_sub));
@@ -1693,7 +1735,8 @@ int rt_device_info(int dev, char *buf, size_t cap) {
 int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (!out) return fail(RT_E_INVALID, "out is NULL");
     *out = nullptr;
-    int rc = validate(D);
+    int tree_depth = 0; // the tree's real depth (a caller may state more, never less)
+    int rc = validate(D, &tree_depth);
     if (rc) return rc;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -1861,7 +1904,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     rt_scene *s = new (std::nothrow) rt_scene();
     if (!s) return fail(RT_E_NOMEM, "out of host memory");
     s->dev = dev;
-    s->tree_depth = D->tree_depth;
+    s->tree_depth = tree_depth;
     rc = upload(&s->pool, pool);
     if (!rc) rc = upload(&s->lhdr, lhdr);
     if (!rc) rc = upload(&s->tshade, tsh);
@@ -1872,20 +1915,31 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 
     int deep_from = DEEP_TREE;
     if (const char *e = getenv("RT_HIP_DEEP_TREE")) deep_from = atoi(e); // tuning / test knob: 0 = always the 8-level ring
-    s->deep = D->tree_depth >= deep_from;
+    s->deep = tree_depth >= deep_from;
     const KernelCfg cfg = s->deep ? CFG_DEEP : CFG_SHALLOW;
     s->slots = cfg.slots;
     const int LDS_STACK = cfg.ring;
     // persistent grid: as many workgroups as the chip holds at this kernel's occupancy
     hipDeviceProp_t pr;
-    int per_cu = 0;
-    if (hipGetDeviceProperties(&pr, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel<false>(true, s->deep), WAVE, 0) != hipSuccess || per_cu < 1)
+    {
+        const hipError_t pe = hipGetDeviceProperties(&pr, dev);
+        if (pe != hipSuccess || pr.multiProcessorCount < 1) {
+            rt_free_scene(s);
+            return fail(RT_E_DEVICE, "hipGetDeviceProperties(%d): %s", dev, hipGetErrorString(pe));
+        }
+    }
+    // (the two instances this scene can run -- render and explicit rays -- each get the grid that fills the chip at
+    // their own occupancy; the per-slot state arrays are sized for the larger one)
+    int per_cu = 0, per_cu_t = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel<false>(sph_root != 0, s->deep), WAVE, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pick_kernel<true>(sph_root != 0, s->deep), WAVE, 0) != hipSuccess || per_cu_t < 1)
+        per_cu_t = 4;
     s->grid = pr.multiProcessorCount * per_cu;
-    const int n_slots = s->grid * slot_stride(s->slots);
+    s->grid_trace = pr.multiProcessorCount * per_cu_t;
+    const int n_slots = std::max(s->grid, s->grid_trace) * slot_stride(s->slots);
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
-    const int need_depth = D->tree_depth + 3 * cull_depth + 5 + (sph_root ? 1 : 0);
+    const int need_depth = tree_depth + 3 * cull_depth + 5 + (sph_root ? 1 : 0);
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK + 1 : 0; // levels that can move to HBM
     if ((long long)ovf_depth * n_slots >= (1ll << 31)) {
         rt_free_scene(s);
@@ -1903,6 +1957,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&s->ev0);
     if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_tables, hipEventDisableTiming);
     if (e != hipSuccess) {
         rt_free_scene(s);
         return fail(RT_E_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
@@ -1952,6 +2007,7 @@ int rt_free_scene(rt_scene *s) {
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->ev_tables) (void)hipEventDestroy(s->ev_tables);
     delete s;
     return RT_OK;
 }
@@ -1972,17 +2028,19 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
     HIP_TRY(hipMemset(s->d_stats, 0, sizeof(h)));
     stats->rays = h[0]; stats->node_visits = h[1]; stats->tri_tests = h[2]; stats->sph_tests = h[3]; stats->tri_shades = h[4];
     stats->tri_tests_done = h[5]; stats->cull_tests = h[6]; stats->sched_steps = h[7]; stats->sched_lanes = h[8];
+    stats->node_fetches = h[9]; stats->sph_tests_done = h[10];
 #ifdef RT_PROFILE
     {
         static const char *kn[4] = {"node", "cull", "tri", "shade"};
-        const double steps = (double)(h[15] + h[16] + h[17] + h[18]);
+        const unsigned long long *q = h + 11; // vote, four bodies, tail (ticks); steps per kind; triangle step details
+        const double steps = (double)(q[6] + q[7] + q[8] + q[9]);
         if (steps > 0) {
-            fprintf(stderr, "[profile] steps %.0f  ticks/step: vote %.1f tail %.1f\n", steps, h[9] / steps, h[14] / steps);
+            fprintf(stderr, "[profile] steps %.0f  ticks/step: vote %.1f tail %.1f\n", steps, q[0] / steps, q[5] / steps);
             for (int k = 0; k < 4; k++)
-                fprintf(stderr, "[profile]   %-5s steps %5.1f%%  body ticks/step %.1f  share of ticks %.1f%%\n", kn[k], 100.0 * h[15 + k] / steps,
-                        h[15 + k] ? (double)h[10 + k] / h[15 + k] : 0.0, 100.0 * h[10 + k] / (double)(h[9] + h[14] + h[10] + h[11] + h[12] + h[13]));
-            fprintf(stderr, "[profile]   triangle tests per ray: short lists %.1f (hit %.2f), behind boxes %.1f (hit %.2f)\n", (double)h[19] / h[0],
-                    (double)h[20] / h[0], (double)h[21] / h[0], (double)h[22] / h[0]);
+                fprintf(stderr, "[profile]   %-5s steps %5.1f%%  body ticks/step %.1f  share of ticks %.1f%%\n", kn[k], 100.0 * q[6 + k] / steps,
+                        q[6 + k] ? (double)q[1 + k] / q[6 + k] : 0.0, 100.0 * q[1 + k] / (double)(q[0] + q[5] + q[1] + q[2] + q[3] + q[4]));
+            fprintf(stderr, "[profile]   triangle tests per ray: short lists %.1f (hit %.2f), behind boxes %.1f (hit %.2f)\n", (double)q[10] / h[0],
+                    (double)q[11] / h[0], (double)q[12] / h[0], (double)q[13] / h[0]);
         }
     }
 #endif
@@ -2021,14 +2079,15 @@ int rt_render_tile(rt_scene *s, const rt_camera *cam, const rt_tile *tile, const
     }
     (void)hipFree(d_rgb);
     (void)hipFree(d_prim);
-    if (!rc && stats) rc = rt_get_stats(s, stats);
+    rt_stats own; // the counters are fetched (and thereby cleared) whether or not the caller wants them
+    if (!rc) rc = rt_get_stats(s, stats ? stats : &own);
     return rc;
 }
 
 int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, double *tri_t, int32_t *sph_id, double *sph_t,
                   rt_stats *stats) {
     if (!s) return fail(RT_E_INVALID, "scene is NULL");
-    if (n > 0x7FFFFFF0LL) return fail(RT_E_LIMIT, "too many rays in one call");
+    if (n > 0x70000000LL) return fail(RT_E_LIMIT, "too many rays in one call");
     if (n < 0 || (n > 0 && (!rays || !tri_id || !tri_t || !sph_id || !sph_t))) return fail(RT_E_INVALID, "bad ray buffers");
     HIP_TRY(hipSetDevice(s->dev));
     if (n == 0) {
@@ -2047,7 +2106,7 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) e = hipMemset(s->d_counter, 0, 16);
     if (e == hipSuccess) {
         const long long want = (n + s->slots - 1) / s->slots;
-        const int grid = (int)std::min<long long>(s->grid, want); // stay within the slot count the state arrays were sized for
+        const int grid = (int)std::min<long long>(s->grid_trace, want); // stay within the slot count the state arrays were sized for
         rt_params none = {1, 0, 0, 0, 1, 0, 0};
         DevCamera nocam = {};
         const KernelFn kern = pick_kernel<true>(s->d.sph_root != 0, s->deep);
@@ -2064,8 +2123,8 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) e = hipMemcpy(sph_t, d_st, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     (void)hipFree(d_rays); (void)hipFree(d_tt); (void)hipFree(d_st); (void)hipFree(d_ti); (void)hipFree(d_si);
     if (e != hipSuccess) return fail(RT_E_DEVICE, "rt_trace_rays: %s", hipGetErrorString(e));
-    if (stats) return rt_get_stats(s, stats);
-    return RT_OK;
+    rt_stats own;
+    return rt_get_stats(s, stats ? stats : &own);
 }
 
 int rt_debug_fp64(int dev, int op, int64_t n, const double *a, const double *b, double *out) {

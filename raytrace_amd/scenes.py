@@ -315,6 +315,51 @@ def tiny_mixed(seed=0, n_tris=40, n_sph=5):
             "camera": {"o": np.array([0, 0, 165.0]), "d": np.array([0, 0, -1.0])}, "sizex": 48, "sizey": 64}
 
 
+def deep_tree(levels=36, seed=4, size=1000.0, per=6, clutter=1500):
+    """A few hundred triangles whose median-split kd-tree is `levels` + 3 or so nodes deep: cluster k
+    sits at 0.9 of the remaining box along axis k mod 3 and everything after it below 0.4, so every
+    split peels off one cluster (kdtree.cpp:82-95 splits at the middle of the node's box).  The
+    clusters shrink with the box; `clutter` larger triangles spread over the whole box end up on the
+    interior nodes' own lists and in the shallow leaves, so rays find hits on the way down."""
+    rs = np.random.RandomState(seed)
+    w = np.array([size, size, size], np.float64)
+    tris = []
+    for k in range(levels):
+        a = k % 3
+        c = rs.uniform(0.1, 0.9, 3) * w
+        c[a] = 0.9 * w[a]
+        h = 0.02 * w.min()
+        cc = c + rs.uniform(-h, h, (per, 1, 3))
+        tris.append((cc + rs.uniform(-h, h, (per, 3, 3))).reshape(per, 9))
+        w[a] *= 0.4
+    cc = rs.uniform(0.1, 0.9, (per, 1, 3)) * w
+    tris.append((cc + rs.uniform(-0.02, 0.02, (per, 3, 3)) * w).reshape(per, 9))
+    if clutter:
+        cc = rs.uniform(0, 1, (clutter, 1, 3)) ** 3 * size  # denser towards the deep corner
+        tris.append((cc + rs.uniform(-0.15, 0.15, (clutter, 3, 3)) * (cc + 1.0)).reshape(clutter, 9))
+    return {"name": f"deep_tree_{levels}", "meshes": [_mesh(np.concatenate(tris), (.7, .7, .7), DIFF)],
+            "spheres": [_sphere(0.3 * size, (0.5 * size, 1.6 * size, 0.5 * size), (12, 12, 12), (0, 0, 0), DIFF)],
+            "camera": {"o": np.array([0.3 * size, 0.3 * size, 2.2 * size]), "d": np.array([-0.1, -0.1, -1.0])}, "sizex": 48, "sizey": 64}
+
+
+def transformed(scene, scale=1.0, shift=(0.0, 0.0, 0.0)):
+    """The scene uniformly scaled about the origin, then translated (meshes, spheres and camera)."""
+    shift = np.asarray(shift, np.float64)
+    out = dict(scene)
+    out["name"] = scene.get("name", "scene") + f"_x{scale:g}"
+    out["meshes"] = []
+    for m in scene["meshes"]:
+        mm = dict(m)
+        mm["verts"] = np.ascontiguousarray((m["verts"].reshape(-1, 3) * scale + shift).reshape(-1, 9))
+        out["meshes"].append(mm)
+    out["spheres"] = [dict(s, rad=s["rad"] * scale, pos=s["pos"] * scale + shift) for s in scene["spheres"]]
+    if "camera" in scene:
+        # (the reference's camera starts its rays 140 units along the view direction, raytrace.cpp:203; that
+        # offset does not scale with the scene, so the transformed camera only sees the same picture for scale 1)
+        out["camera"] = {"o": scene["camera"]["o"] * scale + shift, "d": scene["camera"]["d"].copy()}
+    return out
+
+
 def write_scene_files(scene, directory, c_samps=4, g_samps=4):
     """Write `scene` as a reference-format scene file (test.txt) plus one OBJ per mesh; returns the
     path of test.txt.  Per-triangle colours are not representable without an MTL and are dropped."""

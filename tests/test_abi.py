@@ -83,5 +83,27 @@ def test_upload_rejects_inconsistent_descriptions_before_touching_the_gpu(ra):
         return a
     rc, msg, _ = try_upload(dup_list)
     assert rc == -1 and "more than one" in msg
+    # tree_depth sizes the traversal stacks: an understated value is rejected (a larger one is allowed)
+    assert good.tree_depth > 1
+    rc, msg, _ = try_upload(lambda d: setattr(d, "tree_depth", good.tree_depth - 1))
+    assert rc == -1 and "tree_depth" in msg and str(good.tree_depth) in msg
+
+    def shared_child(d):  # a node that is the right child of two nodes
+        r = np.ctypeslib.as_array(good.node_right, shape=(good.n_nodes,)).copy()
+        have = np.nonzero(r > 0)[0]
+        assert len(have) >= 2
+        r[have[0]] = r[have[-1]]
+        d.node_right = r.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        return r
+    rc, msg, _ = try_upload(shared_child)
+    assert rc == -1 and ("more than one parent" in msg or "not reachable" in msg), msg
+
+    def orphan(d):  # cut a subtree loose
+        r = np.ctypeslib.as_array(good.node_right, shape=(good.n_nodes,)).copy()
+        r[np.nonzero(r > 0)[0][0]] = -1
+        d.node_right = r.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        return r
+    rc, msg, _ = try_upload(orphan)
+    assert rc == -1 and "not reachable" in msg, msg
     h = ctypes.c_void_p()
     assert D.rt_upload_scene(0, None, ctypes.byref(h)) == -1
