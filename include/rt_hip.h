@@ -171,6 +171,23 @@ int rt_render_tile(rt_scene *s, const rt_camera *cam, const rt_tile *tile, const
 int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int32_t n_tiles,
                            const rt_params *p, double *d_rgb, int32_t *d_prim_id, void *stream);
 
+/*
+ * The same work as rt_render_tiles_device for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The
+ * call allocates and frees nothing: the work counter, the tile tables and the per-pixel sub-pixel buffers that
+ * rt_render_tiles_device keeps in (growing) allocations of the scene live in one fixed array in device memory
+ * that each GPU holds from library load until the process ends (about 25 MiB), which bounds a call to
+ * RT_NOALLOC_MAX_TILES tiles, RT_NOALLOC_MAX_PIXELS pixels and RT_NOALLOC_MAX_BLOCKS blocks of 8 x 8 pixels
+ * (a ragged tile edge takes a block of its own); more is rejected with RT_E_LIMIT.  Results are identical to
+ * rt_render_tiles_device's.  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU --
+ * from any scene, on any stream -- race; order them on one stream or synchronise between them.
+ */
+#define RT_NOALLOC_MAX_TILES 64
+#define RT_NOALLOC_MAX_PIXELS (1 << 18)
+#define RT_NOALLOC_MAX_BLOCKS 8192
+int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int32_t n_tiles,
+                            const rt_params *p, double *d_rgb, int32_t *d_prim_id, void *stream);
+
 /* Work counters summed over every launch on this scene since the previous rt_get_stats call
  * (or since upload); synchronises the last stream used, then clears the counters. */
 int rt_get_stats(rt_scene *s, rt_stats *stats);

@@ -62,7 +62,7 @@ HOST_SYMBOLS = ["rth_scene_new", "rth_scene_free", "rth_add_mesh", "rth_add_sphe
                 "rth_load_scene_file", "rth_build", "rth_desc", "rth_num_tris", "rth_num_spheres", "rth_tonemap",
                 "rth_write_bmp", "rth_last_error"]
 DEVICE_SYMBOLS = ["rt_device_count", "rt_device_info", "rt_upload_scene", "rt_free_scene", "rt_render_tile",
-                  "rt_render_tiles_device", "rt_get_stats", "rt_last_kernel_ms", "rt_trace_rays", "rt_debug_fp64",
+                  "rt_render_tiles_device", "rt_render_tiles_noalloc", "rt_get_stats", "rt_last_kernel_ms", "rt_trace_rays", "rt_debug_fp64",
                   "rt_last_error"]
 
 _host = None
@@ -120,6 +120,7 @@ def device_lib():
                                      C.POINTER(Stats)]
         D.rt_render_tiles_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Tile), C.c_int32, C.POINTER(Params),
                                              C.c_void_p, C.c_void_p, C.c_void_p]
+        D.rt_render_tiles_noalloc.argtypes = D.rt_render_tiles_device.argtypes
         D.rt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         D.rt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         D.rt_trace_rays.argtypes = [C.c_void_p, C.c_int64, _dp, _ip, _dp, _ip, _dp, C.POINTER(Stats)]

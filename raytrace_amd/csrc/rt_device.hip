@@ -44,6 +44,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -1222,6 +1223,50 @@ __global__ void k_fp64(int op, long long n, const double *a, const double *b, do
     out[i] = op == 0 ? a[i] / b[i] : sqrt(a[i]);
 }
 
+// ---- the allocation-free entry point's device memory (rt_render_tiles_noalloc)
+// Everything a render launch needs beyond the scene and the caller's output buffers -- the work counter, the tile
+// table, the block-to-tile table, the sub-pixel shares and their per-pixel counts -- at fixed offsets of ONE array
+// in device memory that exists from the moment the library is loaded.  Each GPU holds its own copy.
+constexpr size_t NA_MAX_PIXELS = RT_NOALLOC_MAX_PIXELS, NA_MAX_TILES = RT_NOALLOC_MAX_TILES, NA_MAX_BLOCKS = RT_NOALLOC_MAX_BLOCKS;
+constexpr size_t na_align(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr size_t NA_OFF_COUNTER = 0, NA_OFF_TILES = 256, NA_OFF_BLK = NA_OFF_TILES + na_align(NA_MAX_TILES * sizeof(DevTile)),
+                 NA_OFF_CNT = NA_OFF_BLK + na_align(NA_MAX_BLOCKS * sizeof(int)),
+                 NA_OFF_SUB = NA_OFF_CNT + na_align(NA_MAX_PIXELS * sizeof(unsigned)),
+                 NA_BYTES = NA_OFF_SUB + na_align(NA_MAX_PIXELS * 12 * sizeof(double));
+static __device__ __align__(256) unsigned char scratch[NA_BYTES];
+
+struct NaTiles { int n; rt_tile t[NA_MAX_TILES]; }; // passed by value: no table travels through host memory
+static_assert(sizeof(NaTiles) <= 3072, "the tile list must fit the kernel argument buffer");
+
+// One workgroup: writes the tile table and the block-to-tile table of the launch into the scratch array and clears
+// the work counter (what launch_render() prepares on the host and copies over).
+__global__ void k_na_setup(NaTiles T, unsigned char *scr) {
+    DevTile *tiles = (DevTile *)(scr + NA_OFF_TILES);
+    int *blk = (int *)(scr + NA_OFF_BLK);
+    __shared__ int first[NA_MAX_TILES + 1];
+    if (threadIdx.x == 0) {
+        long long off = 0;
+        int blocks = 0;
+        for (int i = 0; i < T.n; i++) {
+            DevTile d;
+            d.x0 = T.t[i].x0; d.y0 = T.t[i].y0; d.rows = T.t[i].rows; d.cols = T.t[i].cols;
+            d.out_off = off;
+            d.blk_first = blocks;
+            d.blk_cols = (d.cols + 7) / 8;
+            tiles[i] = d;
+            first[i] = blocks;
+            off += (long long)d.rows * d.cols;
+            blocks += ((d.rows + 7) / 8) * d.blk_cols;
+        }
+        first[T.n] = blocks;
+        unsigned *counter = (unsigned *)(scr + NA_OFF_COUNTER);
+        counter[0] = counter[1] = counter[2] = counter[3] = 0u;
+    }
+    __syncthreads();
+    for (int i = 0; i < T.n; i++)
+        for (int b = first[i] + (int)threadIdx.x; b < first[i + 1]; b += (int)blockDim.x) blk[b] = i;
+}
+
 // ------------------------------------------------------------------------------------ host side
 
 thread_local std::string g_err;
@@ -1626,6 +1671,27 @@ DevCamera make_camera(const rt_camera *c) {
     return k;
 }
 
+// The device address of `scratch` on device `dev` (which must be the current device): in host code the array's name
+// is only a handle for hipGetSymbolAddress, and every GPU has its own copy at its own address.  Looked up once per
+// device and kept.
+constexpr int NA_MAX_DEV = 64;
+std::mutex g_scratch_mu;
+unsigned char *g_scratch_ptr[NA_MAX_DEV];
+int scratch_address(int dev, unsigned char **out) {
+    if (dev < 0 || dev >= NA_MAX_DEV) return fail(RT_E_LIMIT, "device %d: rt_render_tiles_noalloc supports devices 0..%d", dev, NA_MAX_DEV - 1);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        size_t bytes = 0;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        HIP_TRY(hipGetSymbolSize(&bytes, HIP_SYMBOL(scratch)));
+        if (!ptr || bytes != NA_BYTES) return fail(RT_E_DEVICE, "scratch array: address %p, %zu bytes (expected %zu)", ptr, bytes, NA_BYTES);
+        g_scratch_ptr[dev] = (unsigned char *)ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return RT_OK;
+}
+
 int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n_tiles, const rt_params *p, double *d_rgb,
                   int *d_prim, hipStream_t stream) {
     int rc = check_params(cam, p);
@@ -2017,6 +2083,57 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_tile *til
     if (!s) return fail(RT_E_INVALID, "scene is NULL");
     if (!d_rgb) return fail(RT_E_INVALID, "d_rgb is NULL");
     return launch_render(s, cam, tiles, n_tiles, p, d_rgb, d_prim_id, (hipStream_t)stream);
+}
+
+int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int32_t n_tiles, const rt_params *p,
+                            double *d_rgb, int32_t *d_prim_id, void *stream_) {
+    if (!s) return fail(RT_E_INVALID, "scene is NULL");
+    if (!d_rgb) return fail(RT_E_INVALID, "d_rgb is NULL");
+    int rc = check_params(cam, p);
+    if (rc) return rc;
+    if (!tiles || n_tiles < 1) return fail(RT_E_INVALID, "no tiles");
+    if ((size_t)n_tiles > NA_MAX_TILES) return fail(RT_E_LIMIT, "rt_render_tiles_noalloc: %d tiles exceed the maximum of %zu", n_tiles, NA_MAX_TILES);
+    NaTiles T; // on the stack, handed to the set-up kernel by value
+    T.n = n_tiles;
+    long long off = 0, blocks = 0;
+    for (int i = 0; i < n_tiles; i++) {
+        const rt_tile &t = tiles[i];
+        if (t.rows < 1 || t.cols < 1 || t.x0 < 0 || t.y0 < 0 || (long long)t.x0 + t.rows > cam->sizex ||
+            (long long)t.y0 + t.cols > cam->sizey)
+            return fail(RT_E_INVALID, "tile %d (%d,%d,%d,%d) is empty or outside the %d x %d image", i, t.x0, t.y0, t.rows,
+                        t.cols, cam->sizex, cam->sizey);
+        T.t[i] = t;
+        off += (long long)t.rows * t.cols;
+        blocks += (long long)((t.rows + 7) / 8) * ((t.cols + 7) / 8);
+        if ((size_t)off > NA_MAX_PIXELS)
+            return fail(RT_E_LIMIT, "rt_render_tiles_noalloc: more than %zu pixels in one call", NA_MAX_PIXELS);
+        if ((size_t)blocks > NA_MAX_BLOCKS)
+            return fail(RT_E_LIMIT, "rt_render_tiles_noalloc: more than %zu blocks of 8 x 8 pixels in one call", NA_MAX_BLOCKS);
+    }
+    for (int i = n_tiles; i < (int)NA_MAX_TILES; i++) T.t[i] = rt_tile{0, 0, 0, 0};
+    HIP_TRY(hipSetDevice(s->dev));
+    unsigned char *scr = nullptr;
+    rc = scratch_address(s->dev, &scr);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    // the array keeps the previous call's contents: the per-pixel counts must start at zero (the set-up kernel
+    // rewrites the tables and the work counter; the shares are written before they are read)
+    HIP_TRY(hipMemsetAsync(scr + NA_OFF_CNT, 0, (size_t)off * sizeof(unsigned), stream));
+    hipLaunchKernelGGL(k_na_setup, dim3(1), dim3(256), 0, stream, T, scr);
+    HIP_TRY(hipGetLastError());
+    const DevCamera dc = make_camera(cam);
+    const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + s->slots - 1) / s->slots);
+    HIP_TRY(hipEventRecord(s->ev0, stream));
+    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, dc, *p, (const DevTile *)(scr + NA_OFF_TILES), n_tiles,
+                       (unsigned)(blocks * 256), (unsigned *)(scr + NA_OFF_COUNTER), d_rgb, d_prim_id, (const double *)nullptr, (int *)nullptr,
+                       (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats, (double *)(scr + NA_OFF_SUB),
+                       (unsigned *)(scr + NA_OFF_CNT), (const int *)(scr + NA_OFF_BLK));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev1, stream));
+    s->timed = true;
+    s->last_stream = stream;
+    return RT_OK;
 }
 
 int rt_get_stats(rt_scene *s, rt_stats *stats) {

@@ -155,6 +155,13 @@ class DeviceScene:
                                                 C.c_void_p(d_prim_ptr) if d_prim_ptr else None,
                                                 C.c_void_p(stream) if stream else None), "rt_render_tiles_device")
 
+    def render_tiles_noalloc(self, cam, params, tiles, d_rgb_ptr, d_prim_ptr=None, stream=None):
+        """rt_render_tiles_noalloc: as render_tiles_device, but the call allocates nothing (bounded sizes)."""
+        arr = (capi.Tile * len(tiles))(*[capi.Tile(*t) for t in tiles])
+        check_dev(self.D.rt_render_tiles_noalloc(self.h, C.byref(cam), arr, len(tiles), C.byref(params), C.c_void_p(d_rgb_ptr),
+                                                 C.c_void_p(d_prim_ptr) if d_prim_ptr else None,
+                                                 C.c_void_p(stream) if stream else None), "rt_render_tiles_noalloc")
+
     def stats(self):
         st = capi.Stats()
         check_dev(self.D.rt_get_stats(self.h, C.byref(st)), "rt_get_stats")

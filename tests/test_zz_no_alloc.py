@@ -1,0 +1,51 @@
+"""rt_render_tiles_noalloc (the entry point that allocates nothing: its per-launch buffers live in one
+fixed array in device memory) against rt_render_tiles_device through the C ABI: bit-identical
+pixels, ids and work counters, on two calls in a row, the second with a smaller input; sizes beyond
+the array are rejected."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(dev, fn, cam, prm, tiles):
+    import torch
+    from raytrace_amd import frame
+    n = frame.tile_pixels(tiles)
+    buf = torch.full((n, 3), -1.0, dtype=torch.float64, device="cuda:0")
+    ids = torch.full((n,), 12345, dtype=torch.int32, device="cuda:0")
+    dev.stats()
+    fn(cam, prm, tiles, buf.data_ptr(), ids.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = dev.stats()
+    return buf.cpu().numpy(), ids.cpu().numpy(), {k: st[k] for k in ("rays", "node_visits", "tri_tests", "tri_shades", "sph_tests")}
+
+
+def test_noalloc_entry_point_matches_the_allocating_one(ra):
+    from raytrace_amd import frame, scenes
+    sc = scenes.cornell_demo()
+    hs = ra.HostScene(sc)
+    dev = ra.DeviceScene(hs, 0)
+    kw = dict(samps=2, rr_depth=5, rr_mode=1, split_depth=2, hard_depth=64, jitter=1, seed=11)
+    prm = ra.capi.make_params(**kw)
+    # first call: a ragged multi-tile share of a 150 x 210 frame; second call: a smaller frame, fewer tiles
+    for sizex, sizey, tr, tc, every in ((150, 210, 40, 56, 1), (45, 70, 16, 24, 2)):
+        cam = ra.capi.make_camera(sc["camera"]["o"], sc["camera"]["d"], sizex, sizey)
+        tiles = frame.plan_tiles(sizex, sizey, tr, tc)[::every]
+        want = _render(dev, dev.render_tiles_device, cam, prm, tiles)
+        got = _render(dev, dev.render_tiles_noalloc, cam, prm, tiles)
+        assert np.array_equal(got[0], want[0])
+        assert np.array_equal(got[1], want[1])
+        assert got[2] == want[2]
+        assert want[0].min() >= 0 and (want[1] != 12345).all()
+    # the limits are errors, not faults
+    cam = ra.capi.make_camera(sc["camera"]["o"], sc["camera"]["d"], 2048, 2048)
+    import torch
+    buf = torch.zeros((16,), dtype=torch.float64, device="cuda:0")
+    with pytest.raises(ra.capi.RtError, match="pixels"):
+        dev.render_tiles_noalloc(cam, prm, [(0, 0, 1024, 1024)], buf.data_ptr())
+    with pytest.raises(ra.capi.RtError, match="tiles"):
+        dev.render_tiles_noalloc(cam, prm, [(i, 0, 1, 1) for i in range(65)], buf.data_ptr())
+    with pytest.raises(ra.capi.RtError, match="blocks"):
+        dev.render_tiles_noalloc(cam, prm, [(0, 0, 1, 2048)] * 40, buf.data_ptr())
+    dev.close()
