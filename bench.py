@@ -24,10 +24,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np  # noqa: E402
 
 # Algorithmic traffic per unit of work, FP64 layout of the reference's records actually needed:
-B_NODE = 72   # box 48 + split 8 + axis/children/list range 16, per KdTree::check invocation
+B_NODE = 72   # box 48 + split 8 + axis/children/list range 16, per node whose records are fetched (a visit that the
+              # parent's step decides from the child's box fetches nothing and is priced at nothing)
 B_TRI = 72    # three FP64 vertices, per Polygon::intersect
 B_SHADE = 76  # nc, col, lig, type, per shaded triangle hit
-B_SPH = 32    # centre + radius, per Sphere::intersect
+B_SPH = 32    # centre + radius, per Sphere::intersect executed
 B_CULL = 64   # base and step 24 + 24 plane bytes of four boxes + four links 16, per culling record visited (long own lists)
 # FP64 operation counts per unit of work (adds/multiplies/compares; divides and sqrt counted once)
 F_NODE, F_TRI, F_SPH, F_SHADE, F_CULL = 40, 45, 20, 100, 96
@@ -52,19 +53,12 @@ def build_workload(name, sizex, sizey):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(scene, cam_od, sizex, sizey, pkw, budget_s=15.0):
-    """The oracle (CPU restatement of the reference path) on this machine's host cores, on a bounded
-    sample of the same workload: 8x8-pixel blocks on a regular lattice over the frame, as many as
-    fit the time budget."""
-    import pyoracle as po
-    po.build()
-    orc = po.OracleScene(scene)
-    cam = po.make_camera(cam_od[0], cam_od[1], sizex, sizey)
-    prm = po.make_params(**pkw)
-    cores = min(16, os.cpu_count() or 1)
+def _cpu_leg(orc, cam, prm, sizex, sizey, threads, budget_s):
+    """Blocks of 8x8 pixels on nested lattices (3x4, 6x8, 12x16, ... positions) over the frame until the
+    time budget is used.  Returns (rays, seconds, blocks)."""
     rays, t_used, blocks, level = 0, 0.0, 0, 0
     seen = set()
-    while t_used < budget_s and level < 6:  # lattices of 3x4, 6x8, 12x16, ... block positions until the budget is used
+    while t_used < budget_s and level < 6:
         ni, nj = 3 << level, 4 << level
         for i in range(ni):
             for j in range(nj):
@@ -73,14 +67,49 @@ def cpu_baseline(scene, cam_od, sizex, sizey, pkw, budget_s=15.0):
                     continue
                 seen.add((x0, y0))
                 t0 = time.perf_counter()
-                _, _, st = orc.render_tile(cam, prm, x0, y0, min(8, sizex - x0), min(8, sizey - y0), nthreads=cores)
+                _, _, st = orc.render_tile(cam, prm, x0, y0, min(8, sizex - x0), min(8, sizey - y0), nthreads=threads)
                 t_used += time.perf_counter() - t0
                 rays += st["rays"]
                 blocks += 1
         level += 1
-    return {"value": rays / t_used / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{blocks} blocks of 8x8 pixels on nested lattices over the same {sizex}x{sizey} frame, same scene/params, "
-                      f"{rays} rays in {t_used:.1f} s, row-parallel pthreads"}
+    return rays, t_used, blocks
+
+
+def cpu_baseline(scene, cam_od, sizex, sizey, pkw, budget_s=15.0):
+    """The oracle (CPU restatement of the reference path) on this machine's host cores, on a bounded
+    sample of the same workload.  Three legs: all the cores this job may use (the headline figure),
+    ONE thread (how a rank of the reference runs: its OpenMP pragma is commented out,
+    raytrace.cpp:185), and one thread of a build with the reference's own flags (-Ofast
+    -march=native, CMakeLists.txt:30; not IEEE-reproducible, for information)."""
+    import pyoracle as po
+    po.build()
+    orc = po.OracleScene(scene)
+    cam = po.make_camera(cam_od[0], cam_od[1], sizex, sizey)
+    prm = po.make_params(**pkw)
+    visible = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = visible
+    # a one-GPU job's share of the host is 16 CPUs even where the machine shows many more
+    cores = max(1, min(allowed, int(os.environ.get("OMP_NUM_THREADS", "16") or 16)))
+    rays, t_used, blocks = _cpu_leg(orc, cam, prm, sizex, sizey, cores, budget_s)
+    r1, t1, b1 = _cpu_leg(orc, cam, prm, sizex, sizey, 1, budget_s / 3)
+    out = {"value": rays / t_used / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "host_cpus_visible": visible, "host_cpus_allowed": allowed,
+           "sample": f"{blocks} blocks of 8x8 pixels on nested lattices over the same {sizex}x{sizey} frame, same scene/params, "
+                     f"{rays} rays in {t_used:.1f} s, pixel-parallel pthreads",
+           "single_thread": {"value": r1 / t1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                             "sample": f"{b1} blocks of 8x8 pixels, {r1} rays in {t1:.1f} s"}}
+    try:
+        fast = po.OracleScene(scene, library=po.build_fast())
+        r2, t2, b2 = _cpu_leg(fast, cam, prm, sizex, sizey, 1, budget_s / 3)
+        out["single_thread_ofast_native"] = {"value": r2 / t2 / 1e6, "unit": "Mrays/s", "cores": 1,
+                                             "flags": "-Ofast -march=native (the reference's CMakeLists.txt:30)",
+                                             "sample": f"{b2} blocks of 8x8 pixels, {r2} rays in {t2:.1f} s"}
+    except Exception as e:  # no compiler on this host: the leg is informational
+        out["single_thread_ofast_native"] = {"value": None, "error": str(e)[:200]}
+    return out
 
 
 def main():
@@ -163,10 +192,10 @@ def main():
         per_launch = {k: st[k] / launches for k in st}
         # bytes/flops of the work the kernel EXECUTES (long own lists are culled); the work the
         # reference would do for the same rays (every own-list triangle tested) is reported beside it
-        alg_bytes = (per_launch["node_visits"] * B_NODE + per_launch["tri_tests_done"] * B_TRI + per_launch["cull_tests"] * B_CULL
-                     + per_launch["tri_shades"] * B_SHADE + per_launch["sph_tests"] * B_SPH)
-        alg_flops = (per_launch["node_visits"] * F_NODE + per_launch["tri_tests_done"] * F_TRI + per_launch["cull_tests"] * F_CULL
-                     + per_launch["sph_tests"] * F_SPH + per_launch["rays"] * F_SHADE)
+        alg_bytes = (per_launch["node_fetches"] * B_NODE + per_launch["tri_tests_done"] * B_TRI + per_launch["cull_tests"] * B_CULL
+                     + per_launch["tri_shades"] * B_SHADE + per_launch["sph_tests_done"] * B_SPH)
+        alg_flops = (per_launch["node_fetches"] * F_NODE + per_launch["tri_tests_done"] * F_TRI + per_launch["cull_tests"] * F_CULL
+                     + per_launch["sph_tests_done"] * F_SPH + per_launch["rays"] * F_SHADE)
         ref_bytes = (per_launch["node_visits"] * B_NODE + per_launch["tri_tests"] * B_TRI + per_launch["tri_shades"] * B_SHADE
                      + per_launch["sph_tests"] * B_SPH)
         avg_ms = float(np.mean(kern_ms))
@@ -177,13 +206,16 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from hardware counters cannot be collected inside this process; the figure of the
         # last profiled full-size launch of the same workload is kept in bench_traffic.json (how: its "source")
-        traffic, traffic_source = None, None
-        tf = os.path.join(ROOT, "bench_traffic.json")
+        # (likewise the vector-instruction counters that show what binds the kernel)
+        traffic, traffic_source, valu = None, None, None
+        tf = os.path.join(ROOT, "bench_counters.json")
         if os.path.exists(tf):
             with open(tf) as fh:
                 tj = json.load(fh)
             if (tj["workload"], tj["sizex_rows"], tj["sizey_cols"], tj["samps_per_subpixel"]) == (args.workload, sizex, sizey, args.samps) and world == 1:
                 traffic, traffic_source = tj["traffic_bytes_per_launch"], tj["source"]
+            if tj["workload"] == args.workload and "valu" in tj:
+                valu = dict(tj["valu"], measured_in_this_run=False)
         out = {
             "metric": "Mrays/s (node), Sponza-class 4K depth-5" if args.workload == "sponza" else f"Mrays/s (node), {args.workload}",
             "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,12 +227,17 @@ def main():
                        "parallelism": f"tiles%{world} + gather", "rays_per_frame": rays_total / args.steps},
             "frame_time_ms": elapsed / args.steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms_avg": avg_ms,
+                         "traffic": traffic, "traffic_measured_in_this_run": False if traffic is not None else None,
+                         "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms_avg": avg_ms,
+                         # what the counters say limits this kernel: vector-instruction issue, not bytes
+                         "limiter": "valu_issue" if valu else None, "valu_issue": valu,
                          "per_ray": {"node_visits": per_launch["node_visits"] / max(1, per_launch["rays"]),
+                                     "node_fetches": per_launch["node_fetches"] / max(1, per_launch["rays"]),
+                                     "sph_tests_done": per_launch["sph_tests_done"] / max(1, per_launch["rays"]),
                                      "tri_tests_reference": per_launch["tri_tests"] / max(1, per_launch["rays"]),
                                      "tri_tests_done": per_launch["tri_tests_done"] / max(1, per_launch["rays"]),
                                      "cull_tests": per_launch["cull_tests"] / max(1, per_launch["rays"]),
-                                     "sph_tests": per_launch["sph_tests"] / max(1, per_launch["rays"]),
+                                     "sph_tests_reference": per_launch["sph_tests"] / max(1, per_launch["rays"]),
                                      "sched_steps_x64": 64 * per_launch["sched_steps"] / max(1, per_launch["rays"]),
                                      "alg_bytes": alg_bytes / max(1, per_launch["rays"]),
                                      "reference_bytes": ref_bytes / max(1, per_launch["rays"])},

@@ -55,6 +55,18 @@ def build(force=False):
             subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
+def build_fast():
+    """The oracle compiled with the reference's own flags (-Ofast -march=native, CMakeLists.txt:30) for
+    THIS machine's CPU, into a temporary directory (a -march=native binary must not travel).  Returns
+    the loaded library.  Not IEEE-reproducible: used only for an informational CPU timing."""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="oracle_fast_")
+    so = os.path.join(d, "liboracle_fast.so")
+    subprocess.check_call(["gcc", "-Ofast", "-march=native", "-fPIC", "-std=c11", "-D_GNU_SOURCE", "-shared", "-o", so,
+                           os.path.join(_HERE, "rt_oracle.c"), "-lm", "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return _bind(C.CDLL(so))
+
+
 _lib = None
 
 
@@ -64,36 +76,39 @@ def lib():
         so = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
-        L = C.CDLL(so)
-        L.orc_scene_new.restype = C.c_void_p
-        L.orc_scene_free.argtypes = [C.c_void_p]
-        L.orc_add_object.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int]
-        L.orc_add_sphere.argtypes = [C.c_void_p, C.c_double, _dp, _dp, _dp, C.c_int]
-        L.orc_build.argtypes = [C.c_void_p]
-        for f in ("orc_num_nodes", "orc_tree_depth", "orc_num_tris"):
-            getattr(L, f).argtypes = [C.c_void_p]
-            getattr(L, f).restype = C.c_int
-        L.orc_tree_dump.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _ip, _ip, _ip, _ip]
-        L.orc_trace.argtypes = [C.c_void_p, C.c_int, _dp, _ip, _dp, _ip, _dp, C.POINTER(OStats)]
-        L.orc_tri_intersect.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
-        L.orc_tri_intersect.restype = C.c_double
-        L.orc_tri_getn.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
-        L.orc_tri_nc.argtypes = [C.c_void_p, C.c_int, _dp]
-        L.orc_sph_intersect.argtypes = [C.c_void_p, C.c_int, _dp]
-        L.orc_sph_intersect.restype = C.c_double
-        L.orc_path_state.argtypes = [C.c_uint64, C.c_uint64]
-        L.orc_path_state.restype = C.c_uint64
-        L.orc_rng_draw.argtypes = [C.POINTER(C.c_uint64)]
-        L.orc_rng_draw.restype = C.c_double
-        L.orc_camera_basis.argtypes = [C.POINTER(OCamera), _dp, _dp, _dp]
-        L.orc_render_tile.argtypes = [C.c_void_p, C.POINTER(OCamera), C.POINTER(OParams), C.c_int, C.c_int, C.c_int,
-                                      C.c_int, _dp, _ip, C.POINTER(OStats), C.c_int]
-        L.orc_radiance.argtypes = [C.c_void_p, C.POINTER(OParams), C.c_int, _dp, _dp, C.POINTER(OStats)]
-        L.orc_draw_pixels.argtypes = [_dp, C.c_size_t, C.POINTER(C.c_ubyte)]
-        L.orc_check_aabb.argtypes = [_dp, _dp]
-        L.orc_primary_ray.argtypes = [_dp, _dp, _dp]
-        _lib = L
+        _lib = _bind(C.CDLL(so))
     return _lib
+
+
+def _bind(L):
+    L.orc_scene_new.restype = C.c_void_p
+    L.orc_scene_free.argtypes = [C.c_void_p]
+    L.orc_add_object.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int]
+    L.orc_add_sphere.argtypes = [C.c_void_p, C.c_double, _dp, _dp, _dp, C.c_int]
+    L.orc_build.argtypes = [C.c_void_p]
+    for f in ("orc_num_nodes", "orc_tree_depth", "orc_num_tris"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = C.c_int
+    L.orc_tree_dump.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _ip, _ip, _ip, _ip]
+    L.orc_trace.argtypes = [C.c_void_p, C.c_int, _dp, _ip, _dp, _ip, _dp, C.POINTER(OStats)]
+    L.orc_tri_intersect.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+    L.orc_tri_intersect.restype = C.c_double
+    L.orc_tri_getn.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+    L.orc_tri_nc.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.orc_sph_intersect.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.orc_sph_intersect.restype = C.c_double
+    L.orc_path_state.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_path_state.restype = C.c_uint64
+    L.orc_rng_draw.argtypes = [C.POINTER(C.c_uint64)]
+    L.orc_rng_draw.restype = C.c_double
+    L.orc_camera_basis.argtypes = [C.POINTER(OCamera), _dp, _dp, _dp]
+    L.orc_render_tile.argtypes = [C.c_void_p, C.POINTER(OCamera), C.POINTER(OParams), C.c_int, C.c_int, C.c_int,
+                                  C.c_int, _dp, _ip, C.POINTER(OStats), C.c_int]
+    L.orc_radiance.argtypes = [C.c_void_p, C.POINTER(OParams), C.c_int, _dp, _dp, C.POINTER(OStats)]
+    L.orc_draw_pixels.argtypes = [_dp, C.c_size_t, C.POINTER(C.c_ubyte)]
+    L.orc_check_aabb.argtypes = [_dp, _dp]
+    L.orc_primary_ray.argtypes = [_dp, _dp, _dp]
+    return L
 
 
 def make_params(samps=1, rr_depth=5, rr_mode=1, split_depth=2, hard_depth=64, jitter=1, seed=1):
@@ -115,8 +130,8 @@ def _c3(v):
 class OracleScene:
     """The oracle's scene: mesh objects (in order), spheres (in order), kd-tree."""
 
-    def __init__(self, scene=None):
-        self.L = lib()
+    def __init__(self, scene=None, library=None):
+        self.L = library if library is not None else lib()
         self.h = C.c_void_p(self.L.orc_scene_new())
         self.built = False
         if scene is not None:
