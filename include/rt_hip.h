@@ -73,6 +73,18 @@ typedef struct rt_scene_desc {
     const double *sph_lig;     /* [n_spheres][3] Sphere::lig */
     const double *sph_col;     /* [n_spheres][3] Sphere::col */
     const int32_t *sph_type;   /* [n_spheres]    Sphere::type */
+
+    /* Textures: Polygon::getcol with an image (polygon.h:30-35,73-89).  n_textures == 0 (what a zero-initialised
+     * description says): every triangle has its plain colour tri_col, and the pointers below may be NULL. */
+    int32_t n_textures;
+    const uint8_t *tex_data;   /* the images back to back, each as loadImage leaves it in Object::tex[k]
+                                  (opencvlib.cpp:21-29): tex_sizey rows of tex_sizex BGR pixels, 3 bytes each */
+    const int64_t *tex_offset; /* [n_textures]  first byte of image k in tex_data */
+    const int32_t *tex_sizex;  /* [n_textures]  Polygon::sizex = image columns (opencvlib.cpp:19) */
+    const int32_t *tex_sizey;  /* [n_textures]  Polygon::sizey = image rows    (opencvlib.cpp:20) */
+    const int32_t *tri_tex;    /* [n_tris]      image of the triangle, -1 = none (Polygon::tex == NULL) */
+    const double *tri_ts;      /* [n_tris][6]   Polygon::ts[0..2] (x, y): the face's texture coordinates (object.cpp:280);
+                                  read only where tri_tex >= 0 */
 } rt_scene_desc;
 
 /* Camera as the scene file gives it (raytrace.cpp:148-151); the basis vectors cx, cy and the

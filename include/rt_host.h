@@ -41,17 +41,44 @@ void rth_scene_free(rth_scene *s);
 int rth_add_mesh(rth_scene *s, const double *verts, int64_t n_tris, const double *lig, const double *col,
                  const double *tri_cols, int type);
 
+/* One texture image as cv::imread hands it to loadImage (opencvlib.cpp:15): rows x cols pixels of BGR bytes,
+ * row-major, top row first.  Returns the image index used by rth_set_mesh_textures. */
+int rth_add_texture(rth_scene *s, const uint8_t *bgr, int32_t rows, int32_t cols);
+
+/* loadImage (opencvlib.cpp:11-30) without OpenCV: reads a 24- or 32-bit uncompressed BMP or a binary PPM (P6),
+ * resizes it to (int)(cols*times) x (int)(rows*times) and adds it.  times == 1 copies the image, as cv::resize does
+ * for equal sizes; other factors follow cv::resize's bilinear (INTER_LINEAR) fixed-point arithmetic as published,
+ * which no OpenCV build was available to check against.  Returns the image index; RT_E_INVALID if the file cannot be
+ * read (the reference then leaves the material untextured, which is what rth_add_obj_file does with this result). */
+int rth_load_texture_file(rth_scene *s, const char *path, double times);
+
+/* Texture coordinates and images for the triangles of object `mesh` (index from rth_add_mesh): tri_tex[n] = image
+ * index or -1 (Polygon::tex == NULL), tri_ts[n][6] = Polygon::ts[0..2] (x, y). */
+int rth_set_mesh_textures(rth_scene *s, int mesh, const int32_t *tri_tex, const double *tri_ts);
+
 /* One Sphere (raytrace.cpp:133-145). Returns the sphere index. */
 int rth_add_sphere(rth_scene *s, double rad, const double *pos, const double *lig, const double *col, int type);
 
-/* Object::readfile (object.cpp:9-286) for an untextured Wavefront OBJ: scale, rotate (degrees,
- * Rx*Ry*Rz), translate; triangles only (a 4th vertex on an `f` line is dropped, as there). */
+/* Object::readfile (object.cpp:9-286) for a Wavefront OBJ with its MTL library: scale, rotate (degrees,
+ * Rx*Ry*Rz), translate; per-material colour (Kd for DIFF objects, Ks otherwise) and texture (map_Kd / map_Ks,
+ * scaled by the object's scale as the reference does); triangles only (a 4th vertex on an `f` line is dropped,
+ * as there).  Image paths are tried relative to the OBJ's directory, then as given. */
 int rth_add_obj_file(rth_scene *s, const char *path, double scale, const double *loc, const double *rot_deg,
                      const double *lig, const double *col, int type);
+
+/* The same reader with extensions the reference does not have (flags == 0 is rth_add_obj_file):
+ *   RTH_OBJ_TRIANGULATE  faces of more than three vertices become a fan of triangles (v0, v_k, v_k+1)
+ *   RTH_OBJ_NEGATIVE     negative (relative) vertex / texture indices are resolved, as the OBJ format defines them */
+#define RTH_OBJ_TRIANGULATE 1u
+#define RTH_OBJ_NEGATIVE 2u
+int rth_add_obj_file_ex(rth_scene *s, const char *path, double scale, const double *loc, const double *rot_deg,
+                        const double *lig, const double *col, int type, unsigned flags);
 
 /* The reference's scene file (raytrace.cpp:106-151). OBJ paths are resolved relative to the
  * scene file's directory. */
 int rth_load_scene_file(rth_scene *s, const char *path, rth_settings *out);
+/* ... reading its OBJ files with rth_add_obj_file_ex(flags). */
+int rth_load_scene_file_ex(rth_scene *s, const char *path, rth_settings *out, unsigned obj_flags);
 
 /* kd-tree build (kdtree.cpp:6-96) + pre-order flattening. Must be called after the last add. */
 int rth_build(rth_scene *s);

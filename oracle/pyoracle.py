@@ -85,6 +85,9 @@ def _bind(L):
     L.orc_scene_free.argtypes = [C.c_void_p]
     L.orc_add_object.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int]
     L.orc_add_sphere.argtypes = [C.c_void_p, C.c_double, _dp, _dp, _dp, C.c_int]
+    L.orc_add_texture.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int]
+    L.orc_set_textures.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
+    L.orc_tri_getcol.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, _dp]
     L.orc_build.argtypes = [C.c_void_p]
     for f in ("orc_num_nodes", "orc_tree_depth", "orc_num_tris"):
         getattr(L, f).argtypes = [C.c_void_p]
@@ -135,11 +138,30 @@ class OracleScene:
         self.h = C.c_void_p(self.L.orc_scene_new())
         self.built = False
         if scene is not None:
+            for t in scene.get("textures", []):
+                self.add_texture(t)
             for m in scene["meshes"]:
-                self.add_object(m["verts"], m["lig"], m["col"], m["type"], m.get("tri_cols"), m.get("vnormals"))
+                o = self.add_object(m["verts"], m["lig"], m["col"], m["type"], m.get("tri_cols"), m.get("vnormals"))
+                if m.get("tri_tex") is not None:
+                    self.set_textures(o, m["tri_tex"], m["tri_ts"])
             for s in scene["spheres"]:
                 self.add_sphere(s["rad"], s["pos"], s["lig"], s["col"], s["type"])
             self.build()
+
+    def add_texture(self, bgr):
+        """bgr: uint8 array [rows, cols, 3]"""
+        a = np.ascontiguousarray(bgr, dtype=np.uint8)
+        return self.L.orc_add_texture(self.h, a.ctypes.data_as(C.POINTER(C.c_ubyte)), a.shape[0], a.shape[1])
+
+    def set_textures(self, obj, tri_tex, tri_ts):
+        tt = np.ascontiguousarray(tri_tex, dtype=np.int32)
+        ts = np.ascontiguousarray(tri_ts, dtype=np.float64).reshape(-1, 6)
+        self.L.orc_set_textures(self.h, int(obj), _i(tt), _d(ts))
+
+    def tri_getcol(self, gid, u, v):
+        out = np.zeros(3)
+        self.L.orc_tri_getcol(self.h, int(gid), float(u), float(v), _d(out))
+        return out
 
     def __del__(self):
         try:
@@ -270,6 +292,9 @@ def ref_lib():
         R.ref_free.argtypes = [C.c_void_p]
         R.ref_add_object.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int]
         R.ref_add_sphere.argtypes = [C.c_void_p, C.c_double, _dp, _dp, _dp, C.c_int]
+        R.ref_add_texture.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int]
+        R.ref_add_object_tex.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, _dp]
+        R.ref_poly_getcol.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
         R.ref_build.argtypes = [C.c_void_p]
         R.ref_check.argtypes = [C.c_void_p, _dp, _ip, _ip, _dp]
         R.ref_sphere_intersect.argtypes = [C.c_void_p, _dp, _ip, _dp]
@@ -296,19 +321,34 @@ class RefScene:
         self.h = C.c_void_p(self.R.ref_new())
         self.offsets = [0]
         if scene is not None:
+            for t in scene.get("textures", []):
+                a = np.ascontiguousarray(t, dtype=np.uint8)
+                self.R.ref_add_texture(self.h, a.ctypes.data_as(C.POINTER(C.c_ubyte)), a.shape[0], a.shape[1])
             for m in scene["meshes"]:
-                self.add_object(m["verts"], m["lig"], m["col"], m["type"], m.get("tri_cols"), m.get("vnormals"))
+                self.add_object(m["verts"], m["lig"], m["col"], m["type"], m.get("tri_cols"), m.get("vnormals"),
+                                m.get("tri_tex"), m.get("tri_ts"))
             for s in scene["spheres"]:
                 self.add_sphere(s["rad"], s["pos"], s["lig"], s["col"], s["type"])
             self.build()
 
-    def add_object(self, verts, lig, col, type_, tri_cols=None, vnormals=None):
+    def add_object(self, verts, lig, col, type_, tri_cols=None, vnormals=None, tri_tex=None, tri_ts=None):
         v = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 9)
         tc = None if tri_cols is None else np.ascontiguousarray(tri_cols, dtype=np.float64).reshape(-1, 3)
         vn = None if vnormals is None else np.ascontiguousarray(vnormals, dtype=np.float64).reshape(-1, 9)
         self.offsets.append(self.offsets[-1] + v.shape[0])
+        if tri_tex is not None:  # Polygons built by the reference's constructor with its tex / sizex / sizey / ts arguments
+            tt = np.ascontiguousarray(tri_tex, dtype=np.int32)
+            ts = np.ascontiguousarray(tri_ts, dtype=np.float64).reshape(-1, 6)
+            return self.R.ref_add_object_tex(self.h, _d(v), v.shape[0], _d(_c3(lig)), _d(_c3(col)),
+                                             None if tc is None else _d(tc), None if vn is None else _d(vn), int(type_), _i(tt), _d(ts))
         return self.R.ref_add_object(self.h, _d(v), v.shape[0], _d(_c3(lig)), _d(_c3(col)),
                                      None if tc is None else _d(tc), None if vn is None else _d(vn), int(type_))
+
+    def poly_getcol(self, gid, u, v):
+        no, nv = self.split_gid(gid)
+        out = np.zeros(3)
+        self.R.ref_poly_getcol(self.h, no, nv, float(u), float(v), _d(out))
+        return out
 
     def add_sphere(self, rad, pos, lig, col, type_):
         return self.R.ref_add_sphere(self.h, float(rad), _d(_c3(pos)), _d(_c3(lig)), _d(_c3(col)), int(type_))

@@ -10,7 +10,7 @@
 //     KdTree::KdTree / create      (kdtree.cpp:6-96)
 //     KdTree::check / check_node   (kdtree.cpp:98-142)
 //     KdTreeNode::check_aabb       (kdtree.h:57-76)
-//     Polygon ctor (nc) / intersect / getn   (polygon.h:17-72)
+//     Polygon ctor (nc) / intersect / getn / GetImageData / getcol   (polygon.h:17-89)
 //     Sphere::intersect, sphere_intersect    (sphere.h:13-21, sphere.cpp:3-14)
 //     Point3D / Ray                          (point.h)
 // raytrace.cpp (radiance, main) is NOT part of this build: it needs mpi.h and OpenCV,
@@ -23,7 +23,9 @@
 #include "sphere.h"
 #include "kdtree.h"
 
+struct RefTex { std::vector<unsigned char> data; int sizex, sizey; };
 struct RefScene {
+    std::vector<RefTex *> texs; // stable addresses: Polygons keep raw pointers into them
     std::vector<Object> objs;
     std::vector<Sphere> spheres;
     KdTree *tree;
@@ -59,6 +61,45 @@ int ref_add_object(void *h, const double *verts, int ntri, const double *lig, co
         o.polys.push_back(Polygon(p, n, ts, o.lig, c, o.type, NULL, 0, 0));
     }
     return (int)s->objs.size() - 1;
+}
+
+// One image as loadImage leaves it (opencvlib.cpp:19-29): rows x cols BGR bytes, sizex = cols, sizey = rows.
+int ref_add_texture(void *h, const unsigned char *bgr, int rows, int cols) {
+    RefScene *s = (RefScene *)h;
+    RefTex *t = new RefTex();
+    t->data.assign(bgr, bgr + 3 * (size_t)rows * cols);
+    t->sizex = cols; t->sizey = rows;
+    s->texs.push_back(t);
+    return (int)s->texs.size() - 1;
+}
+
+// As ref_add_object, with the constructor's texture arguments: tri_tex[i] = image or -1, tri_ts[i][6] = ts[0..2].xy.
+int ref_add_object_tex(void *h, const double *verts, int ntri, const double *lig, const double *col,
+                       const double *tri_cols, const double *vnormals, int type, const int *tri_tex, const double *tri_ts) {
+    RefScene *s = (RefScene *)h;
+    s->objs.push_back(Object());
+    Object &o = s->objs.back();
+    o.lig = Point3D(lig[0], lig[1], lig[2]);
+    o.col = Point3D(col[0], col[1], col[2]);
+    o.type = (RType)type;
+    for (int i = 0; i < ntri; i++) {
+        Point3D p[3], n[3], ts[3];
+        for (int k = 0; k < 3; k++) {
+            p[k] = Point3D(verts[9 * i + 3 * k], verts[9 * i + 3 * k + 1], verts[9 * i + 3 * k + 2]);
+            n[k] = vnormals ? Point3D(vnormals[9 * i + 3 * k], vnormals[9 * i + 3 * k + 1], vnormals[9 * i + 3 * k + 2]) : p[k];
+            ts[k] = Point3D(tri_ts[6 * i + 2 * k], tri_ts[6 * i + 2 * k + 1], 0);
+        }
+        Point3D c = tri_cols ? Point3D(tri_cols[3 * i], tri_cols[3 * i + 1], tri_cols[3 * i + 2]) : o.col;
+        RefTex *t = tri_tex[i] >= 0 ? s->texs[tri_tex[i]] : NULL;
+        o.polys.push_back(Polygon(p, n, ts, o.lig, c, o.type, t ? &t->data[0] : NULL, t ? t->sizex : 0, t ? t->sizey : 0));
+    }
+    return (int)s->objs.size() - 1;
+}
+
+void ref_poly_getcol(void *h, int no, int nv, double u, double v, double *out) {
+    RefScene *s = (RefScene *)h;
+    Point3D c = s->objs[no].polys[nv].getcol(u, v);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
 }
 
 int ref_add_sphere(void *h, double rad, const double *pos, const double *lig, const double *col, int type) {

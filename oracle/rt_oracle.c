@@ -12,7 +12,7 @@
  *   polygon.h:23-27        face normal nc (6-term expansion, then normalised)
  *   polygon.h:37-60        Moller-Trumbore, two sided, det<eps rejected
  *   polygon.h:61-72        getn (returns nc unless the s[] guard fails)
- *   polygon.h:73-89        getcol (untextured branch: the polygon colour)
+ *   polygon.h:30-35,73-89  GetImageData / getcol (plain colour, or the texture image)
  *   sphere.h:13-21         ray/sphere roots filtered by >eps
  *   sphere.cpp:3-14        brute-force scan from the LAST sphere down, strict <
  *   kdtree.h:36-76         box init/update and check_aabb
@@ -80,7 +80,11 @@ typedef struct {
     v3 nc;     /* face normal */
     v3 col;    /* polygon colour */
     int obj;   /* owning object (its lig/type are used for shading, raytrace.cpp:66) */
+    int tex;   /* texture image or -1 (Polygon::tex == NULL) */
+    v3 ts[3];  /* texture coordinates of the vertices (Polygon::ts; z = 0) */
 } otri;
+
+typedef struct { unsigned char *data; int sizex, sizey; } otex; /* Polygon::tex/sizex/sizey: sizex = image columns, sizey = rows */
 
 typedef struct { v3 lig; int type; int first, count; } oobj;
 typedef struct { double rad; v3 pos, lig, col; int type; } osph;
@@ -98,6 +102,7 @@ typedef struct {
     otri *tris; int ntris, captris;
     oobj *objs; int nobjs, capobjs;
     osph *sphs; int nsphs, capsphs;
+    otex *texs; int ntexs, captexs;
     onode *root;
     double (*tmi)[3], (*tma)[3]; /* per-triangle boxes (KdTreeNode ctor, kdtree.h:29-34) */
     int nnodes, depth;
@@ -119,7 +124,8 @@ static void free_node(onode *t) {
 void orc_scene_free(oscene *s) {
     if (!s) return;
     free_node(s->root);
-    free(s->tris); free(s->objs); free(s->sphs); free(s->tmi); free(s->tma);
+    for (int i = 0; i < s->ntexs; i++) free(s->texs[i].data);
+    free(s->tris); free(s->objs); free(s->sphs); free(s->texs); free(s->tmi); free(s->tma);
     free(s);
 }
 
@@ -153,10 +159,36 @@ int orc_add_object(oscene *s, const double *verts, int ntri, const double *lig, 
         t->nc = vnorm(t->nc);
         t->col = tri_cols ? V(tri_cols[3 * i], tri_cols[3 * i + 1], tri_cols[3 * i + 2]) : V(col[0], col[1], col[2]);
         t->obj = s->nobjs;
+        t->tex = -1;
+        for (int k = 0; k < 3; k++) t->ts[k] = V(0, 0, 0);
     }
     s->ntris += ntri;
     s->nobjs++;
     return s->nobjs - 1;
+}
+
+/* One texture image: rows x cols BGR pixels, row-major, as loadImage stores it (opencvlib.cpp:21-29);
+ * Polygon::sizex = cols, Polygon::sizey = rows (opencvlib.cpp:19-20). Returns the image index. */
+int orc_add_texture(oscene *s, const unsigned char *bgr, int rows, int cols) {
+    if (s->ntexs == s->captexs) {
+        s->captexs = s->captexs ? 2 * s->captexs : 8;
+        s->texs = (otex *)realloc(s->texs, sizeof(otex) * s->captexs);
+    }
+    otex *t = &s->texs[s->ntexs];
+    t->data = (unsigned char *)malloc(3 * (size_t)rows * cols);
+    memcpy(t->data, bgr, 3 * (size_t)rows * cols);
+    t->sizex = cols; t->sizey = rows;
+    return s->ntexs++;
+}
+
+/* Images and texture coordinates (6 doubles per triangle: ts[0..2].xy) for the triangles of object `obj`. */
+void orc_set_textures(oscene *s, int obj, const int *tri_tex, const double *tri_ts) {
+    const oobj *o = &s->objs[obj];
+    for (int i = 0; i < o->count; i++) {
+        otri *t = &s->tris[o->first + i];
+        t->tex = tri_tex[i];
+        for (int k = 0; k < 3; k++) t->ts[k] = V(tri_ts[6 * i + 2 * k], tri_ts[6 * i + 2 * k + 1], 0);
+    }
 }
 
 int orc_add_sphere(oscene *s, double rad, const double *pos, const double *lig, const double *col, int type) {
@@ -287,6 +319,30 @@ static v3 tri_getn(const otri *p, v3 x) {
     return vscale(ans, (double)(1.0 / (s[0] + s[1] + s[2])));
 }
 
+/* polygon.h:30-35.  The reference indexes the image unchecked: coordinates outside [0, 1) can give a negative
+ * remainder and an index outside the image (undefined behaviour there).  Policy here and in the HIP path: a value
+ * that does not fit an int, or an index outside the image, reads as 0. */
+static double image_data(const otex *t, double x, double y, int c) {
+    const double fx = x * t->sizex + 0.5, fy = y * t->sizey + 0.5;
+    if (!(fabs(fx) < 2147483648.0) || !(fabs(fy) < 2147483648.0)) return 0;
+    const long long idx = (long long)((int)fx % t->sizex) * 3 * t->sizey + 3 * (long long)((int)fy % t->sizey) + c;
+    if (idx < 0 || idx >= 3ll * t->sizex * t->sizey) return 0;
+    return t->data[idx];
+}
+
+/* polygon.h:73-89 */
+static v3 tri_getcol(const oscene *sc, const otri *p, double u, double v) {
+    if (p->tex < 0) return p->col;
+    const otex *t = &sc->texs[p->tex];
+    v3 s = vadd(vadd(vscale(vsub(p->ts[1], p->ts[0]), u), vscale(vsub(p->ts[2], p->ts[0]), v)), p->ts[0]);
+    v3 ans;
+    ans.x = image_data(t, s.x, s.y, 2);
+    ans.y = image_data(t, s.x, s.y, 1);
+    ans.z = image_data(t, s.x, s.y, 0);
+    ans.x = pow(ans.x / 256, 2.2); ans.y = pow(ans.y / 256, 2.2); ans.z = pow(ans.z / 256, 2.2);
+    return ans;
+}
+
 /* sphere.h:13-21 */
 static double sph_intersect(const osph *s, const ray_t *r) {
     v3 op = vsub(s->pos, r->o);
@@ -401,6 +457,10 @@ void orc_tri_getn(const oscene *sc, int gid, const double *x, double *out) {
 void orc_tri_nc(const oscene *sc, int gid, double *out) {
     out[0] = sc->tris[gid].nc.x; out[1] = sc->tris[gid].nc.y; out[2] = sc->tris[gid].nc.z;
 }
+void orc_tri_getcol(const oscene *sc, int gid, double u, double v, double *out) {
+    v3 c = tri_getcol(sc, &sc->tris[gid], u, v);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
 double orc_sph_intersect(const oscene *sc, int i, const double *ray) {
     ray_t r = {V(ray[0], ray[1], ray[2]), V(ray[3], ray[4], ray[5])};
     return sph_intersect(&sc->sphs[i], &r);
@@ -477,7 +537,7 @@ static v3 radiance(octx *c, ray_t r, int depth, int into) {
         x = vadd(r.o, vscale(r.d, to));
         n = tri_getn(p, x);
         nl = (vdot(n, r.d) < 0 ? n : vscale(n, -1));
-        f = p->col; /* getcol, untextured (polygon.h:75) */
+        f = tri_getcol(sc, p, u, v); /* raytrace.cpp:65 */
         type = sc->objs[p->obj].type; lig = sc->objs[p->obj].lig;
         if (primary) c->first_id = idt;
         c->st.tri_shades++;

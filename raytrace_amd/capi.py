@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 RT_DIFF, RT_SPEC, RT_REFR = 0, 1, 2
+RTH_OBJ_TRIANGULATE, RTH_OBJ_NEGATIVE = 1, 2
 RT_ID_MISS = -2147483648
 
 _dp = C.POINTER(C.c_double)
@@ -27,6 +28,8 @@ class SceneDesc(C.Structure):
         ("tree_depth", C.c_int32),
         ("n_tris", C.c_int32), ("tri_verts", _dp), ("tri_nc", _dp), ("tri_col", _dp), ("tri_lig", _dp), ("tri_type", _ip),
         ("n_spheres", C.c_int32), ("sph_rad", _dp), ("sph_pos", _dp), ("sph_lig", _dp), ("sph_col", _dp), ("sph_type", _ip),
+        ("n_textures", C.c_int32), ("tex_data", C.POINTER(C.c_uint8)), ("tex_offset", C.POINTER(C.c_int64)), ("tex_sizex", _ip),
+        ("tex_sizey", _ip), ("tri_tex", _ip), ("tri_ts", _dp),
     ]
 
 
@@ -58,8 +61,9 @@ class Settings(C.Structure):
                 ("num_per_node", C.c_int32), ("cu_stack_size", C.c_int32), ("view", C.c_double * 3), ("dir", C.c_double * 3)]
 
 
-HOST_SYMBOLS = ["rth_scene_new", "rth_scene_free", "rth_add_mesh", "rth_add_sphere", "rth_add_obj_file",
-                "rth_load_scene_file", "rth_build", "rth_desc", "rth_num_tris", "rth_num_spheres", "rth_tonemap",
+HOST_SYMBOLS = ["rth_scene_new", "rth_scene_free", "rth_add_mesh", "rth_add_sphere", "rth_add_obj_file", "rth_add_obj_file_ex",
+                "rth_add_texture", "rth_load_texture_file", "rth_set_mesh_textures",
+                "rth_load_scene_file", "rth_load_scene_file_ex", "rth_build", "rth_desc", "rth_num_tris", "rth_num_spheres", "rth_tonemap",
                 "rth_write_bmp", "rth_last_error"]
 DEVICE_SYMBOLS = ["rt_device_count", "rt_device_info", "rt_upload_scene", "rt_free_scene", "rt_render_tile",
                   "rt_render_tiles_device", "rt_render_tiles_noalloc", "rt_get_stats", "rt_last_kernel_ms", "rt_trace_rays", "rt_debug_fp64",
@@ -81,7 +85,12 @@ def host_lib():
         H.rth_add_mesh.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, _dp, _dp, C.c_int]
         H.rth_add_sphere.argtypes = [C.c_void_p, C.c_double, _dp, _dp, _dp, C.c_int]
         H.rth_add_obj_file.argtypes = [C.c_void_p, C.c_char_p, C.c_double, _dp, _dp, _dp, _dp, C.c_int]
+        H.rth_add_obj_file_ex.argtypes = [C.c_void_p, C.c_char_p, C.c_double, _dp, _dp, _dp, _dp, C.c_int, C.c_uint]
+        H.rth_add_texture.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]
+        H.rth_load_texture_file.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        H.rth_set_mesh_textures.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
         H.rth_load_scene_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Settings)]
+        H.rth_load_scene_file_ex.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Settings), C.c_uint]
         H.rth_build.argtypes = [C.c_void_p]
         H.rth_desc.argtypes = [C.c_void_p]
         H.rth_desc.restype = C.POINTER(SceneDesc)

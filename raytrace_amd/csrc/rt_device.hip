@@ -156,6 +156,18 @@ struct __attribute__((aligned(16))) TriShade {
 };
 static_assert(sizeof(TriShade) == 80, "TriShade must be 80 bytes");
 
+// A textured triangle's texture coordinates and image (Polygon::ts, tex, sizex, sizey; polygon.h:13-15); TriShade::type
+// carries its index + 1 above the two type bits.  `off` is the image's first byte in the texture block.
+struct __attribute__((aligned(16))) TexTri {
+    double ts[6];
+    unsigned long long off;
+    int sizex, sizey;
+};
+static_assert(sizeof(TexTri) == 64, "TexTri must be 64 bytes");
+// The texture block in HBM: pow(b / 256, 2.2) for the 256 byte values (evaluated by the host's libm, which is what
+// the CPU path calls, polygon.h:87), then the TexTri records, then the images.
+constexpr size_t TEX_OFF_TRI = 256 * sizeof(double);
+
 struct __attribute__((aligned(16))) SphGeom { double px, py, pz, rad; };
 struct __attribute__((aligned(16))) SphShade { double lig[3], col[3]; int type, pad0; double pad1; };
 static_assert(sizeof(SphShade) == 64, "SphShade must be 64 bytes");
@@ -166,6 +178,7 @@ struct DevScene {
     const uint2 *tlist; // per triangle (device position): first list position of its own list, its own list position
     const SphGeom *sph;
     const SphShade *sshade;
+    const unsigned char *tex; // texture block (see TexTri), NULL without textures
     unsigned *ovf;  // overflow stack [ovf_depth][n_slots]
     double *lstate; // per-slot state kept in HBM [LS_WORDS][n_slots]
     double cen[3]; // centre of the scene's vertex box
@@ -321,6 +334,37 @@ __device__ __forceinline__ void trace_spheres(const DevScene &S, d3 o, d3 d, dou
     }
 }
 
+// The u, v that Polygon::intersect leaves behind for a ray that hits (polygon.h:37-60; raytrace.cpp:61 calls it a
+// second time just for them), with E1, E2 precomputed by the same subtractions.
+__device__ __forceinline__ void tri_uv(d3 p0, d3 E1, d3 E2, d3 o, d3 d, double &u, double &v) {
+    const d3 P = cross(d, E2);
+    double det = dot(E1, P);
+    d3 Tv;
+    if (det > 0) Tv = o - p0;
+    else { Tv = p0 - o; det = -det; }
+    u = dot(Tv, P);
+    const d3 Q = cross(Tv, E1);
+    v = dot(d, Q);
+    const double fInvDet = 1.0 / det;
+    u *= fInvDet;
+    v *= fInvDet;
+}
+
+// Polygon::getcol with an image (polygon.h:30-35,73-89).  A coordinate that does not fit an int, or an index outside
+// the image (the reference reads out of bounds there), gives the byte 0.
+__device__ __forceinline__ d3 tex_color(const unsigned char *blk, const TexTri &x, double u, double v) {
+    const double sx = ((x.ts[2] - x.ts[0]) * u + (x.ts[4] - x.ts[0]) * v) + x.ts[0];
+    const double sy = ((x.ts[3] - x.ts[1]) * u + (x.ts[5] - x.ts[1]) * v) + x.ts[1];
+    const double fx = sx * x.sizex + 0.5, fy = sy * x.sizey + 0.5;
+    const double *powtab = (const double *)blk;
+    long long idx = -1;
+    if (fabs(fx) < 2147483648.0 && fabs(fy) < 2147483648.0)
+        idx = (long long)((int)fx % x.sizex) * 3 * x.sizey + 3 * (long long)((int)fy % x.sizey);
+    if (idx < 0 || idx + 2 >= 3ll * x.sizex * x.sizey) { const double z = powtab[0]; return mk(z, z, z); }
+    const unsigned char *px = blk + x.off + idx;
+    return mk(powtab[px[2]], powtab[px[1]], powtab[px[0]]);
+}
+
 __device__ __forceinline__ double clamp01(double x) { return x < 0 ? 0 : x > 1 ? 1 : x; } // raytrace.cpp:28-31
 
 // sin and cos of x in [0, 2*pi) (the only argument range radiance() needs, raytrace.cpp:79-81):
@@ -431,7 +475,8 @@ __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30
 
 // SPH = true: the scene has a sphere hierarchy (a second instance, so that scenes without one do not pay for it).
 // SLOTS, LDS_STACK: see KernelCfg.
-template <bool TRACE, bool SPH, int SLOTS, int LDS_STACK>
+// TEX = true: the scene has textured triangles (an instance of its own, like SPH).
+template <bool TRACE, bool SPH, bool TEX, int SLOTS, int LDS_STACK>
 __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCamera cam, rt_params P, const DevTile *tiles, int n_tiles,
                                                              unsigned n_work, unsigned *counter, double *rgb, int *prim,
                                                              const double *rays, int *tri_id, double *tri_t, int *sph_id,
@@ -961,6 +1006,17 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                             x = o + d * to;
                             n = ld3(sh->nc);
                             f = ld3(sh->col); type = sh->type; lig = ld3(sh->lig);
+                            if (TEX) { // getcol(u, v) of a textured triangle (raytrace.cpp:61,65)
+                                const unsigned tt = (unsigned)type >> 2;
+                                type &= 3;
+                                if (tt) {
+                                    const double2 *p = (const double2 *)(S.pool + (size_t)(2u * S.g_list + 3u * (S.g_list >> 2) + 5u * (unsigned)tpos) * 16);
+                                    const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+                                    double u, v;
+                                    tri_uv(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d, u, v);
+                                    f = tex_color(S.tex, ((const TexTri *)(S.tex + TEX_OFF_TRI))[tt - 1], u, v);
+                                }
+                            }
                             if (primary && sub == 0 && smp == 0 && prim) prim[outk] = sh->gid;
                             ev_shade = true;
                         }
@@ -1292,7 +1348,7 @@ int fail(int code, const char *fmt, ...) {
 struct rt_scene {
     int dev = 0;
     DevScene d{};
-    void *pool = nullptr, *tshade = nullptr, *tlist = nullptr, *sph = nullptr, *sshade = nullptr;
+    void *pool = nullptr, *tshade = nullptr, *tlist = nullptr, *sph = nullptr, *sshade = nullptr, *tex = nullptr;
     void *ovf = nullptr, *lstate = nullptr, *lhdr = nullptr;
     int tree_depth = 0;
     int grid = 0, grid_trace = 0; // persistent workgroups of the render / explicit-ray kernel
@@ -1319,10 +1375,16 @@ struct rt_scene {
 
 using KernelFn = void (*)(DevScene, DevCamera, rt_params, const DevTile *, int, unsigned, unsigned *, double *, int *, const double *, int *,
                           double *, int *, double *, unsigned long long *, double *, unsigned *, const int *);
+template <bool TRACE, bool TEX>
+KernelFn pick_kernel2(bool sph, bool deep) {
+    if (deep) return sph ? k_main<TRACE, true, TEX, CFG_DEEP.slots, CFG_DEEP.ring> : k_main<TRACE, false, TEX, CFG_DEEP.slots, CFG_DEEP.ring>;
+    return sph ? k_main<TRACE, true, TEX, CFG_SHALLOW.slots, CFG_SHALLOW.ring> : k_main<TRACE, false, TEX, CFG_SHALLOW.slots, CFG_SHALLOW.ring>;
+}
+// (explicit-ray queries never shade: they have no textured instance)
 template <bool TRACE>
-KernelFn pick_kernel(bool sph, bool deep) {
-    if (deep) return sph ? k_main<TRACE, true, CFG_DEEP.slots, CFG_DEEP.ring> : k_main<TRACE, false, CFG_DEEP.slots, CFG_DEEP.ring>;
-    return sph ? k_main<TRACE, true, CFG_SHALLOW.slots, CFG_SHALLOW.ring> : k_main<TRACE, false, CFG_SHALLOW.slots, CFG_SHALLOW.ring>;
+KernelFn pick_kernel(bool sph, bool deep, bool tex) {
+    if (!TRACE && tex) return pick_kernel2<false, true>(sph, deep);
+    return pick_kernel2<TRACE, false>(sph, deep);
 }
 
 namespace {
@@ -1630,6 +1692,16 @@ int validate(const rt_scene_desc *D, int *real_depth) {
         if (D->tri_type[i] < 0 || D->tri_type[i] > 2) return fail(RT_E_INVALID, "triangle %d: type %d", i, D->tri_type[i]);
     for (int i = 0; i < D->n_spheres; i++)
         if (D->sph_type[i] < 0 || D->sph_type[i] > 2) return fail(RT_E_INVALID, "sphere %d: type %d", i, D->sph_type[i]);
+    if (D->n_textures < 0) return fail(RT_E_INVALID, "n_textures is negative");
+    if (D->n_textures > 0) {
+        if (!D->tex_data || !D->tex_offset || !D->tex_sizex || !D->tex_sizey || !D->tri_tex || !D->tri_ts)
+            return fail(RT_E_INVALID, "texture arrays missing");
+        for (int k = 0; k < D->n_textures; k++)
+            if (D->tex_sizex[k] < 1 || D->tex_sizey[k] < 1 || D->tex_offset[k] < 0 || (long long)D->tex_sizex[k] * D->tex_sizey[k] > (1ll << 28))
+                return fail(RT_E_INVALID, "texture %d: %d x %d pixels at offset %lld", k, D->tex_sizey[k], D->tex_sizex[k], (long long)D->tex_offset[k]);
+        for (int i = 0; i < D->n_tris; i++)
+            if (D->tri_tex[i] < -1 || D->tri_tex[i] >= D->n_textures) return fail(RT_E_INVALID, "triangle %d: texture %d of %d", i, D->tri_tex[i], D->n_textures);
+    }
     return RT_OK;
 }
 
@@ -1762,7 +1834,7 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     const DevCamera dc = make_camera(cam);
     const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + s->slots - 1) / s->slots);
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep);
+    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep, s->d.tex != nullptr);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, dc, *p, (const DevTile *)s->d_tiles, n_tiles,
                        (unsigned)(blocks * 256), s->d_counter, d_rgb, d_prim, (const double *)nullptr, (int *)nullptr,
                        (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats, s->d_sub, s->d_subcnt, (const int *)s->d_blk_tile);
@@ -1922,6 +1994,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         if (D->node_count[i] > 0) last[(size_t)D->node_first[i] + D->node_count[i] - 1] = 1;
     double blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0}, lg2 = 0; // vertex box and longest edge of the scene
     std::vector<TriShade> tsh((size_t)D->n_tris);
+    std::vector<TexTri> textri;
     std::vector<unsigned> list_first((size_t)D->n_list, 0); // by list position: where its own list starts
     for (int i = 0; i < D->n_nodes; i++)
         for (int k = 0; k < D->node_count[i]; k++) list_first[(size_t)D->node_first[i] + k] = (unsigned)D->node_first[i];
@@ -1956,6 +2029,31 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         }
         h.type = D->tri_type[g];
         h.gid = g;
+        if (D->n_textures > 0 && D->tri_tex[g] >= 0) { // (images are laid out below, in index order)
+            TexTri x;
+            for (int k = 0; k < 6; k++) x.ts[k] = D->tri_ts[6 * (size_t)g + k];
+            x.off = (unsigned long long)D->tri_tex[g]; // replaced by the image's offset in the block below
+            x.sizex = D->tex_sizex[D->tri_tex[g]];
+            x.sizey = D->tex_sizey[D->tri_tex[g]];
+            textri.push_back(x);
+            if (textri.size() >= (1u << 29)) return fail(RT_E_LIMIT, "too many textured triangles");
+            h.type |= (int)((unsigned)textri.size() << 2);
+        }
+    }
+    const size_t n_textri = textri.size();
+    std::vector<unsigned char> texblk;
+    if (n_textri) {
+        std::vector<unsigned long long> img_off((size_t)D->n_textures);
+        size_t at = TEX_OFF_TRI + n_textri * sizeof(TexTri);
+        for (int k = 0; k < D->n_textures; k++) { img_off[k] = at; at += 3 * (size_t)D->tex_sizex[k] * D->tex_sizey[k]; }
+        texblk.resize((at + 15) & ~(size_t)15);
+        double powtab[256];
+        for (int b = 0; b < 256; b++) powtab[b] = std::pow((double)b / 256, 2.2); // polygon.h:87
+        memcpy(texblk.data(), powtab, sizeof(powtab));
+        for (TexTri &x : textri) x.off = img_off[(size_t)x.off];
+        memcpy(texblk.data() + TEX_OFF_TRI, textri.data(), n_textri * sizeof(TexTri));
+        for (int k = 0; k < D->n_textures; k++)
+            memcpy(texblk.data() + img_off[k], D->tex_data + D->tex_offset[k], 3 * (size_t)D->tex_sizex[k] * D->tex_sizey[k]);
     }
     std::vector<SphGeom> sg((size_t)D->n_spheres);
     std::vector<SphShade> ss((size_t)D->n_spheres);
@@ -1977,6 +2075,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (!rc) rc = upload(&s->tlist, tls);
     if (!rc) rc = upload(&s->sph, sg);
     if (!rc) rc = upload(&s->sshade, ss);
+    if (!rc && n_textri) rc = upload(&s->tex, texblk);
     if (rc) { rt_free_scene(s); return rc; }
 
     int deep_from = DEEP_TREE;
@@ -1997,9 +2096,9 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     // (the two instances this scene can run -- render and explicit rays -- each get the grid that fills the chip at
     // their own occupancy; the per-slot state arrays are sized for the larger one)
     int per_cu = 0, per_cu_t = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel<false>(sph_root != 0, s->deep), WAVE, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel<false>(sph_root != 0, s->deep, n_textri != 0), WAVE, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pick_kernel<true>(sph_root != 0, s->deep), WAVE, 0) != hipSuccess || per_cu_t < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pick_kernel<true>(sph_root != 0, s->deep, false), WAVE, 0) != hipSuccess || per_cu_t < 1)
         per_cu_t = 4;
     s->grid = pr.multiProcessorCount * per_cu;
     s->grid_trace = pr.multiProcessorCount * per_cu_t;
@@ -2033,6 +2132,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->d.tlist = (const uint2 *)s->tlist;
     s->d.sph = (const SphGeom *)s->sph;
     s->d.sshade = (const SphShade *)s->sshade;
+    s->d.tex = n_textri ? (const unsigned char *)s->tex : nullptr;
     s->d.ovf = (unsigned *)s->ovf;
     s->d.lstate = (double *)s->lstate;
     s->d.reach = std::sqrt(lg2) * 1.000001;
@@ -2068,7 +2168,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile};
+    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -2124,7 +2224,7 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
     const DevCamera dc = make_camera(cam);
     const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + s->slots - 1) / s->slots);
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep);
+    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep, s->d.tex != nullptr);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, dc, *p, (const DevTile *)(scr + NA_OFF_TILES), n_tiles,
                        (unsigned)(blocks * 256), (unsigned *)(scr + NA_OFF_COUNTER), d_rgb, d_prim_id, (const double *)nullptr, (int *)nullptr,
                        (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats, (double *)(scr + NA_OFF_SUB),
@@ -2226,7 +2326,7 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
         const int grid = (int)std::min<long long>(s->grid_trace, want); // stay within the slot count the state arrays were sized for
         rt_params none = {1, 0, 0, 0, 1, 0, 0};
         DevCamera nocam = {};
-        const KernelFn kern = pick_kernel<true>(s->d.sph_root != 0, s->deep);
+        const KernelFn kern = pick_kernel<true>(s->d.sph_root != 0, s->deep, false);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, nullptr, s->d, nocam, none, (const DevTile *)nullptr, 0,
                            (unsigned)n, s->d_counter, (double *)nullptr, (int *)nullptr, (const double *)d_rays, d_ti, d_tt, d_si,
                            d_st, s->d_stats, (double *)nullptr, (unsigned *)nullptr, (const int *)nullptr);

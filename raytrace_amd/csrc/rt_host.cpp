@@ -3,7 +3,8 @@
 //
 // Reference behaviour restated (not its code):
 //   scene file grammar          raytrace.cpp:106-151
-//   OBJ / MTL reader            object.cpp:9-286 (untextured subset; see rth_add_obj_file)
+//   OBJ / MTL reader            object.cpp:9-286 (see rth_add_obj_file_ex)
+//   texture images              opencvlib.cpp:11-30 (BMP / PPM reader and a bilinear resize instead of OpenCV)
 //   mesh transform              object.cpp:22-23,138-140 and matrix.h:24-52, matrix.cpp:21-37
 //   face normal nc              polygon.h:23-27
 //   kd-tree builder             kdtree.cpp:6-96, kdtree.h:29-55
@@ -12,6 +13,8 @@
 // The builder works on index ranges instead of copying node vectors per level, and skips the
 // three sorted event arrays the reference fills but never reads (kdtree.cpp:10-21), so it also
 // handles meshes of tens of millions of triangles; the tree it produces is the same.
+#include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -55,6 +58,12 @@ struct rth_scene {
     std::vector<Mesh> meshes;
     std::vector<double> sph_rad, sph_pos, sph_lig, sph_col;
     std::vector<int32_t> sph_type;
+    // texture images back to back (rows of BGR pixels) and, per triangle, its image (-1: none) and ts[0..2].xy
+    std::vector<uint8_t> tex_data;
+    std::vector<int64_t> tex_offset;
+    std::vector<int32_t> tex_sizex, tex_sizey; // Polygon::sizex = columns, Polygon::sizey = rows (opencvlib.cpp:19-20)
+    std::vector<int32_t> tri_tex;
+    std::vector<double> tri_ts;
     // flattened tree
     std::vector<double> node_box, node_split;
     std::vector<int32_t> node_axis, node_left, node_right, node_first, node_count, list_tri;
@@ -90,6 +99,13 @@ void refresh_desc(rth_scene *s) {
     d.sph_lig = s->sph_lig.data();
     d.sph_col = s->sph_col.data();
     d.sph_type = s->sph_type.data();
+    d.n_textures = (int32_t)s->tex_offset.size();
+    d.tex_data = s->tex_data.data();
+    d.tex_offset = s->tex_offset.data();
+    d.tex_sizex = s->tex_sizex.data();
+    d.tex_sizey = s->tex_sizey.data();
+    d.tri_tex = s->tri_tex.data();
+    d.tri_ts = s->tri_ts.data();
 }
 
 // polygon.h:23-27: six-term expansion, then norm() = multiply by 1/sqrt (point.h:49-51)
@@ -164,9 +180,151 @@ int rth_add_mesh(rth_scene *s, const double *verts, int64_t n_tris, const double
         }
     }
     s->type.insert(s->type.end(), (size_t)n_tris, type);
+    s->tri_tex.insert(s->tri_tex.end(), (size_t)n_tris, -1);
+    s->tri_ts.insert(s->tri_ts.end(), 6 * (size_t)n_tris, 0.0);
     s->meshes.push_back(m);
     s->built = false;
     return (int)s->meshes.size() - 1;
+}
+
+int rth_add_texture(rth_scene *s, const uint8_t *bgr, int32_t rows, int32_t cols) {
+    if (!s || !bgr || rows < 1 || cols < 1) return fail(RT_E_INVALID, "rth_add_texture: bad arguments");
+    if ((int64_t)rows * cols > (int64_t)1 << 28) return fail(RT_E_LIMIT, "rth_add_texture: image of %d x %d pixels is too large", rows, cols);
+    s->tex_offset.push_back((int64_t)s->tex_data.size());
+    s->tex_sizex.push_back(cols);
+    s->tex_sizey.push_back(rows);
+    s->tex_data.insert(s->tex_data.end(), bgr, bgr + 3 * (size_t)rows * cols);
+    if (s->built) refresh_desc(s); // images are not part of the tree
+    return (int)s->tex_offset.size() - 1;
+}
+
+int rth_set_mesh_textures(rth_scene *s, int mesh, const int32_t *tri_tex, const double *tri_ts) {
+    if (!s || !tri_tex || !tri_ts || mesh < 0 || (size_t)mesh >= s->meshes.size()) return fail(RT_E_INVALID, "rth_set_mesh_textures: bad arguments");
+    const Mesh &m = s->meshes[mesh];
+    for (int64_t i = 0; i < m.count; i++) {
+        if (tri_tex[i] < -1 || tri_tex[i] >= (int32_t)s->tex_offset.size())
+            return fail(RT_E_INVALID, "rth_set_mesh_textures: triangle %lld names image %d of %zu", (long long)i, tri_tex[i], s->tex_offset.size());
+        s->tri_tex[(size_t)(m.first + i)] = tri_tex[i];
+        for (int k = 0; k < 6; k++) s->tri_ts[6 * (size_t)(m.first + i) + k] = tri_ts[6 * i + k];
+    }
+    return RT_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+// An image file as rows x cols BGR bytes, top row first (what cv::imread returns for a colour image).
+bool read_image(const char *path, std::vector<uint8_t> &bgr, int &rows, int &cols) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    std::vector<uint8_t> raw;
+    uint8_t chunk[65536];
+    size_t n;
+    while ((n = fread(chunk, 1, sizeof(chunk), f)) > 0) raw.insert(raw.end(), chunk, chunk + n);
+    fclose(f);
+    auto le32 = [&](size_t o) { return (uint32_t)raw[o] | ((uint32_t)raw[o + 1] << 8) | ((uint32_t)raw[o + 2] << 16) | ((uint32_t)raw[o + 3] << 24); };
+    if (raw.size() >= 54 && raw[0] == 'B' && raw[1] == 'M') { // BMP, uncompressed 24 or 32 bits per pixel
+        const uint32_t off = le32(10), hdr = le32(14);
+        const int32_t w = (int32_t)le32(18), h = (int32_t)le32(22);
+        const int bpp = raw[28] | (raw[29] << 8);
+        const uint32_t comp = le32(30);
+        if (hdr < 40 || w < 1 || h == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && !(comp == 3 && bpp == 32))) return false;
+        const int ah = h < 0 ? -h : h;
+        const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
+        if ((size_t)off + stride * ah > raw.size()) return false;
+        rows = ah; cols = w;
+        bgr.resize(3 * (size_t)rows * cols);
+        for (int r = 0; r < rows; r++) {
+            const uint8_t *src = &raw[off + stride * (size_t)(h < 0 ? r : rows - 1 - r)]; // bottom-up unless the height is negative
+            for (int c = 0; c < cols; c++)
+                for (int k = 0; k < 3; k++) bgr[3 * ((size_t)r * cols + c) + k] = src[(size_t)c * (bpp / 8) + k];
+        }
+        return true;
+    }
+    if (raw.size() >= 11 && raw[0] == 'P' && raw[1] == '6') { // binary PPM: RGB bytes
+        size_t p = 2;
+        long v[3];
+        for (int k = 0; k < 3; k++) {
+            for (;;) { // white space and comment lines
+                while (p < raw.size() && isspace(raw[p])) p++;
+                if (p < raw.size() && raw[p] == '#') { while (p < raw.size() && raw[p] != '\n') p++; continue; }
+                break;
+            }
+            long x = 0;
+            bool any = false;
+            while (p < raw.size() && raw[p] >= '0' && raw[p] <= '9') { x = x * 10 + (raw[p] - '0'); p++; any = true; if (x > 1 << 28) return false; }
+            if (!any) return false;
+            v[k] = x;
+        }
+        p++; // the single white-space byte after maxval
+        if (v[0] < 1 || v[1] < 1 || v[2] < 1 || v[2] > 255 || p + 3 * (size_t)v[0] * (size_t)v[1] > raw.size()) return false;
+        cols = (int)v[0]; rows = (int)v[1];
+        bgr.resize(3 * (size_t)rows * cols);
+        for (size_t i = 0; i < (size_t)rows * cols; i++) { bgr[3 * i] = raw[p + 3 * i + 2]; bgr[3 * i + 1] = raw[p + 3 * i + 1]; bgr[3 * i + 2] = raw[p + 3 * i]; }
+        return true;
+    }
+    return false;
+}
+
+// cv::resize(src, dst, Size(dc, dr)) with its default bilinear interpolation for 8-bit images, as OpenCV publishes
+// it: sample position (d + 0.5) * scale - 0.5, weights as 11-bit fixed point, horizontal pass in int, vertical pass
+// (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.  Equal sizes copy.
+void resize_bilinear(const std::vector<uint8_t> &src, int sr, int sc, std::vector<uint8_t> &dst, int dr, int dc) {
+    dst.resize(3 * (size_t)dr * dc);
+    if (sr == dr && sc == dc) { dst = src; return; }
+    const double scale_x = 1.0 / ((double)dc / sc), scale_y = 1.0 / ((double)dr / sr);
+    std::vector<int> xofs((size_t)dc), yofs((size_t)dr);
+    std::vector<short> alpha(2 * (size_t)dc), beta(2 * (size_t)dr);
+    auto coef = [](float w) { long r = lrintf(w * 2048.0f); return (short)(r < -32768 ? -32768 : r > 32767 ? 32767 : r); };
+    for (int dx = 0; dx < dc; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)std::floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sc - 1) { fx = 0; sx = sc - 1; }
+        xofs[dx] = sx;
+        alpha[2 * dx] = coef(1.f - fx); alpha[2 * dx + 1] = coef(fx);
+    }
+    for (int dy = 0; dy < dr; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = (int)std::floor(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        beta[2 * dy] = coef(1.f - fy); beta[2 * dy + 1] = coef(fy);
+    }
+    std::vector<int> row0(3 * (size_t)dc), row1(3 * (size_t)dc);
+    for (int dy = 0; dy < dr; dy++) {
+        const int y0 = std::min(std::max(yofs[dy], 0), sr - 1), y1 = std::min(std::max(yofs[dy] + 1, 0), sr - 1);
+        const uint8_t *s0 = &src[3 * (size_t)y0 * sc], *s1 = &src[3 * (size_t)y1 * sc];
+        for (int dx = 0; dx < dc; dx++) {
+            const int sx = xofs[dx], sx1 = std::min(sx + 1, sc - 1);
+            for (int k = 0; k < 3; k++) {
+                row0[3 * dx + k] = s0[3 * sx + k] * alpha[2 * dx] + s0[3 * sx1 + k] * alpha[2 * dx + 1];
+                row1[3 * dx + k] = s1[3 * sx + k] * alpha[2 * dx] + s1[3 * sx1 + k] * alpha[2 * dx + 1];
+            }
+        }
+        const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+        for (int x = 0; x < 3 * dc; x++) {
+            const int v = (((b0 * (row0[x] >> 4)) >> 16) + ((b1 * (row1[x] >> 4)) >> 16) + 2) >> 2;
+            dst[3 * (size_t)dy * dc + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int rth_load_texture_file(rth_scene *s, const char *path, double times) {
+    if (!s || !path) return fail(RT_E_INVALID, "rth_load_texture_file: bad arguments");
+    std::vector<uint8_t> img, out;
+    int rows = 0, cols = 0;
+    if (!read_image(path, img, rows, cols)) return fail(RT_E_INVALID, "Can't read image %s (24/32-bit BMP or binary PPM expected)", path);
+    const int dc = (int)(cols * times), dr = (int)(rows * times); // opencvlib.cpp:16
+    if (dc < 1 || dr < 1) return fail(RT_E_INVALID, "%s: scaled to %d x %d pixels", path, dr, dc);
+    resize_bilinear(img, rows, cols, out, dr, dc);
+    return rth_add_texture(s, out.data(), dr, dc);
 }
 
 int rth_add_sphere(rth_scene *s, double rad, const double *pos, const double *lig, const double *col, int type) {
@@ -265,6 +423,11 @@ const rt_scene_desc *rth_desc(const rth_scene *s) {
 
 int rth_add_obj_file(rth_scene *s, const char *path, double scale, const double *loc, const double *rot_deg,
                      const double *lig, const double *col, int type) {
+    return rth_add_obj_file_ex(s, path, scale, loc, rot_deg, lig, col, type, 0u);
+}
+
+int rth_add_obj_file_ex(rth_scene *s, const char *path, double scale, const double *loc, const double *rot_deg,
+                        const double *lig, const double *col, int type, unsigned flags) {
     if (!s || !path || !loc || !rot_deg || !lig || !col) return fail(RT_E_INVALID, "rth_add_obj_file: bad arguments");
     FILE *fp = fopen(path, "r");
     if (!fp) return fail(RT_E_INVALID, "Can't open %s", path); // object.cpp:25-28
@@ -276,12 +439,22 @@ int rth_add_obj_file(rth_scene *s, const char *path, double scale, const double 
     dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
 
     std::vector<P3> points;
+    std::vector<P3> vt(1, P3{0, 0, 0});                   // object.cpp:21: texture coordinates are 1-based, slot 0 is (0, 0)
     std::vector<std::string> name(1);
     std::vector<P3> cols(1, P3{col[0], col[1], col[2]}); // object.cpp:17-18: slot 0 = the object's colour
-    std::vector<int> face, face_mtl;
+    std::vector<int> tex(1, -1);                          // object.cpp:15: slot 0 has no image
+    std::vector<int> face, face_t, face_mtl;
     int ntex = 0, lines = 0;
     char buf[512], str[512];
     int rc = RT_OK;
+    // one vertex reference of a face: v, v/t, v//n or v/t/n (object.cpp:195-249); returns false if it has no vertex index
+    auto parse_ref = [](const char *tok, int &v, int &tt) {
+        tt = 0;
+        if (sscanf(tok, "%d", &v) != 1) return false;
+        const char *sl = strchr(tok, '/');
+        if (sl && sl[1] != '/' && sl[1] != 0) { if (sscanf(sl + 1, "%d", &tt) != 1) tt = 0; }
+        return true;
+    };
     while (rc == RT_OK && fscanf(fp, "%511s", buf) != EOF) {
         lines++;
         switch (buf[0]) {
@@ -292,7 +465,7 @@ int rth_add_obj_file(rth_scene *s, const char *path, double scale, const double 
             ntex = 0;
             for (size_t i = 0; i < name.size(); i++) if (name[i] == str) ntex = (int)i;
             break;
-        case 'm': { // mtllib (object.cpp:51-129); texture maps are treated like a missing image file
+        case 'm': { // mtllib (object.cpp:51-129)
             if (!fgets(buf, sizeof(buf), fp)) break;
             str[0] = 0;
             sscanf(buf, "%511s", str);
@@ -306,6 +479,7 @@ int rth_add_obj_file(rth_scene *s, const char *path, double scale, const double 
                     sscanf(buf, "%511s", str);
                     name.push_back(str);
                     cols.push_back(P3{col[0], col[1], col[2]});
+                    tex.push_back(-1);
                 } else if (buf[0] == 'K' && ((buf[1] == 'd' && type == RT_DIFF) || (buf[1] == 's' && type != RT_DIFF))) {
                     P3 v; // Kd for diffuse objects, Ks otherwise (object.cpp:75-106)
                     if (fscanf(fm, "%lf%lf%lf", &v.x, &v.y, &v.z) != 3) {
@@ -313,6 +487,15 @@ int rth_add_obj_file(rth_scene *s, const char *path, double scale, const double 
                         break;
                     }
                     cols.back() = v;
+                } else if ((!strcmp(buf, "map_Kd") && type == RT_DIFF) || (!strcmp(buf, "map_Ks") && type != RT_DIFF)) {
+                    // object.cpp:112-119: the image of the material read last, scaled by the object's scale; a file
+                    // that cannot be read leaves the material untextured (opencvlib.cpp:13-14)
+                    if (!fgets(buf, sizeof(buf), fm)) break;
+                    str[0] = 0;
+                    sscanf(buf, "%511s", str);
+                    int img = rth_load_texture_file(s, (dir + str).c_str(), scale);
+                    if (img < 0) img = rth_load_texture_file(s, str, scale);
+                    tex.back() = img < 0 ? -1 : img;
                 } else if (!fgets(buf, sizeof(buf), fm)) break;
             }
             fclose(fm);
@@ -328,19 +511,45 @@ int rth_add_obj_file(rth_scene *s, const char *path, double scale, const double 
                 v.x *= scale; v.y *= scale; v.z *= scale;
                 v = apply4(t, v);
                 points.push_back(P3{v.x + loc[0], v.y + loc[1], v.z + loc[2]});
-            } else if (!fgets(buf, sizeof(buf), fp)) { /* vn, vt and anything else: rest of line ignored */ }
+            } else if (buf[1] == 't' && buf[2] == '\0') { // texture coordinate: two values (object.cpp:164-171)
+                P3 v{0, 0, 0};
+                if (fscanf(fp, "%lf%lf", &v.x, &v.y) != 2) {
+                    rc = fail(RT_E_INVALID, "Error: Wrong Number of Values(Should be 3). at Line %d", lines);
+                    break;
+                }
+                vt.push_back(v);
+            } else if (!fgets(buf, sizeof(buf), fp)) { /* vn (the normals never reach the image, polygon.h:67-69) and anything else */ }
             break;
-        case 'f': { // first three vertices of the face (object.cpp:186-257); v, v/t, v//n, v/t/n
-            int v[3] = {0, 0, 0};
+        case 'f': { // the first three vertices of the face (object.cpp:186-257)
+            int v[3] = {0, 0, 0}, tt[3] = {0, 0, 0};
             bool ok = true;
             for (int j = 0; j < 3 && ok; j++) {
                 if (fscanf(fp, "%511s", str) != 1) { ok = false; break; }
-                ok = sscanf(str, "%d", &v[j]) == 1;
+                ok = parse_ref(str, v[j], tt[j]);
             }
             if (!ok) { rc = fail(RT_E_INVALID, "Error: Wrong Face at Line %d", lines); break; }
-            for (int j = 0; j < 3; j++) face.push_back(v[j] - 1);
+            auto resolve = [&](int &vv, int &t2) { // OBJ's relative indices, when asked for
+                if (flags & RTH_OBJ_NEGATIVE) {
+                    if (vv < 0) vv = (int)points.size() + vv + 1;
+                    if (t2 < 0) t2 = (int)vt.size() + t2;
+                }
+            };
+            for (int j = 0; j < 3; j++) resolve(v[j], tt[j]);
+            for (int j = 0; j < 3; j++) { face.push_back(v[j] - 1); face_t.push_back(tt[j]); }
             face_mtl.push_back(ntex);
-            if (!fgets(buf, sizeof(buf), fp)) { /* drop a 4th vertex, if any */ }
+            if (!fgets(buf, sizeof(buf), fp)) buf[0] = 0; // the rest of the line: further vertices, if any
+            if (flags & RTH_OBJ_TRIANGULATE) { // a fan (v0, v_k, v_k+1); the reference drops everything past the third vertex
+                int pv = v[2], pt = tt[2];
+                for (char *tok = strtok(buf, " \t\r\n"); tok; tok = strtok(nullptr, " \t\r\n")) {
+                    int nv, nt;
+                    if (!parse_ref(tok, nv, nt)) break;
+                    resolve(nv, nt);
+                    face.push_back(v[0] - 1); face.push_back(pv - 1); face.push_back(nv - 1);
+                    face_t.push_back(tt[0]); face_t.push_back(pt); face_t.push_back(nt);
+                    face_mtl.push_back(ntex);
+                    pv = nv; pt = nt;
+                }
+            }
             break;
         }
         default: // '#' comments and everything else: eat the rest of the line
@@ -351,19 +560,35 @@ int rth_add_obj_file(rth_scene *s, const char *path, double scale, const double 
     fclose(fp);
     if (rc) return rc;
     const size_t nf = face_mtl.size();
-    std::vector<double> verts(9 * nf), tcols(3 * nf);
-    for (size_t i = 0; i < nf; i++)
+    std::vector<double> verts(9 * nf), tcols(3 * nf), ts(6 * nf);
+    std::vector<int32_t> ttex(nf);
+    bool any_tex = false;
+    for (size_t i = 0; i < nf; i++) {
         for (int j = 0; j < 3; j++) {
             const int p = face[3 * i + j];
             if (p < 0 || (size_t)p >= points.size()) return fail(RT_E_INVALID, "Error face."); // object.cpp:271-277
             verts[9 * i + 3 * j] = points[p].x; verts[9 * i + 3 * j + 1] = points[p].y; verts[9 * i + 3 * j + 2] = points[p].z;
-            const P3 c = cols[face_mtl[i]];
-            tcols[3 * i] = c.x; tcols[3 * i + 1] = c.y; tcols[3 * i + 2] = c.z;
+            const int ti = face_t[3 * i + j];
+            // (the reference indexes vt[] unchecked, object.cpp:280; an index outside the file's coordinates is an error here)
+            if (ti < 0 || (size_t)ti >= vt.size()) return fail(RT_E_INVALID, "Error face.");
+            ts[6 * i + 2 * j] = vt[ti].x; ts[6 * i + 2 * j + 1] = vt[ti].y;
         }
-    return rth_add_mesh(s, verts.data(), (int64_t)nf, lig, col, tcols.data(), type);
+        const P3 c = cols[face_mtl[i]];
+        tcols[3 * i] = c.x; tcols[3 * i + 1] = c.y; tcols[3 * i + 2] = c.z;
+        ttex[i] = tex[face_mtl[i]];
+        any_tex = any_tex || ttex[i] >= 0;
+    }
+    const int mesh = rth_add_mesh(s, verts.data(), (int64_t)nf, lig, col, tcols.data(), type);
+    if (mesh >= 0 && (any_tex || vt.size() > 1)) { // (coordinates are kept even where no image uses them, as Polygon::ts is)
+        const int r2 = rth_set_mesh_textures(s, mesh, ttex.data(), ts.data());
+        if (r2 < 0) return r2;
+    }
+    return mesh;
 }
 
-int rth_load_scene_file(rth_scene *s, const char *path, rth_settings *out) {
+int rth_load_scene_file(rth_scene *s, const char *path, rth_settings *out) { return rth_load_scene_file_ex(s, path, out, 0u); }
+
+int rth_load_scene_file_ex(rth_scene *s, const char *path, rth_settings *out, unsigned obj_flags) {
     if (!s || !path || !out) return fail(RT_E_INVALID, "rth_load_scene_file: bad arguments");
     FILE *fi = fopen(path, "r");
     if (!fi) return fail(RT_E_INVALID, "Can't open %s", path);
@@ -381,7 +606,7 @@ int rth_load_scene_file(rth_scene *s, const char *path, rth_settings *out) {
             break;
         }
         std::string obj = buf[0] == '/' ? std::string(buf) : dir + buf;
-        const int r = rth_add_obj_file(s, obj.c_str(), times, loc, rot, lig, col, type_from_word(buf2));
+        const int r = rth_add_obj_file_ex(s, obj.c_str(), times, loc, rot, lig, col, type_from_word(buf2), obj_flags);
         if (r < 0) rc = r;
     }
     if (rc == RT_OK && (fscanf(fi, "%d", &m) != 1 || m < 0)) rc = fail(RT_E_INVALID, "%s: sphere count", path);

@@ -20,18 +20,22 @@ class HostScene:
         self.h = C.c_void_p(self.H.rth_scene_new())
         self.settings = None
         if scene is not None:
+            for t in scene.get("textures", []):
+                self.add_texture(t)
             for m in scene["meshes"]:
-                self.add_mesh(m["verts"], m["lig"], m["col"], m["type"], m.get("tri_cols"))
+                i = self.add_mesh(m["verts"], m["lig"], m["col"], m["type"], m.get("tri_cols"))
+                if m.get("tri_tex") is not None:
+                    self.set_mesh_textures(i, m["tri_tex"], m["tri_ts"])
             for s in scene["spheres"]:
                 self.add_sphere(s["rad"], s["pos"], s["lig"], s["col"], s["type"])
             self.build()
 
     @classmethod
-    def from_file(cls, path):
+    def from_file(cls, path, obj_flags=0):
         """Load the reference's scene-file format (raytrace.cpp:106-151) and build the tree."""
         self = cls()
         st = capi.Settings()
-        check_host(self.H.rth_load_scene_file(self.h, str(path).encode(), C.byref(st)), "rth_load_scene_file")
+        check_host(self.H.rth_load_scene_file_ex(self.h, str(path).encode(), C.byref(st), int(obj_flags)), "rth_load_scene_file")
         self.settings = st
         self.build()
         return self
@@ -54,9 +58,36 @@ class HostScene:
         return check_host(self.H.rth_add_sphere(self.h, float(rad), dptr(c3(pos)), dptr(c3(lig)), dptr(c3(col)), int(type_)),
                           "rth_add_sphere")
 
-    def add_obj_file(self, path, scale, loc, rot_deg, lig, col, type_):
-        return check_host(self.H.rth_add_obj_file(self.h, str(path).encode(), float(scale), dptr(c3(loc)), dptr(c3(rot_deg)),
-                                                  dptr(c3(lig)), dptr(c3(col)), int(type_)), "rth_add_obj_file")
+    def add_obj_file(self, path, scale, loc, rot_deg, lig, col, type_, flags=0):
+        return check_host(self.H.rth_add_obj_file_ex(self.h, str(path).encode(), float(scale), dptr(c3(loc)), dptr(c3(rot_deg)),
+                                                     dptr(c3(lig)), dptr(c3(col)), int(type_), int(flags)), "rth_add_obj_file")
+
+    def add_texture(self, bgr):
+        """One image, uint8 [rows, cols, 3] in BGR order (what loadImage keeps, opencvlib.cpp:21-29)."""
+        a = np.ascontiguousarray(bgr, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("a texture is a [rows, cols, 3] uint8 array")
+        return check_host(self.H.rth_add_texture(self.h, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[0], a.shape[1]), "rth_add_texture")
+
+    def load_texture_file(self, path, times=1.0):
+        return check_host(self.H.rth_load_texture_file(self.h, str(path).encode(), float(times)), "rth_load_texture_file")
+
+    def set_mesh_textures(self, mesh, tri_tex, tri_ts):
+        tt = np.ascontiguousarray(tri_tex, dtype=np.int32)
+        ts = np.ascontiguousarray(tri_ts, dtype=np.float64).reshape(-1, 6)
+        if ts.shape[0] != tt.shape[0]:
+            raise ValueError("tri_ts must have six values per triangle")
+        return check_host(self.H.rth_set_mesh_textures(self.h, int(mesh), iptr(tt), dptr(ts)), "rth_set_mesh_textures")
+
+    def textures(self):
+        """Copies of the images held by the scene, as [rows, cols, 3] uint8 arrays."""
+        d = self.desc.contents
+        out = []
+        for k in range(d.n_textures):
+            rows, cols = d.tex_sizey[k], d.tex_sizex[k]
+            a = np.ctypeslib.as_array(d.tex_data, shape=(d.tex_offset[k] + 3 * rows * cols,))[d.tex_offset[k]:]
+            out.append(a.reshape(rows, cols, 3).copy())
+        return out
 
     def build(self):
         check_host(self.H.rth_build(self.h), "rth_build")
@@ -89,7 +120,8 @@ class HostScene:
             axis=arr(d.node_axis, nn, np.int32), left=arr(d.node_left, nn, np.int32), right=arr(d.node_right, nn, np.int32),
             first=arr(d.node_first, nn, np.int32), count=arr(d.node_count, nn, np.int32), list=arr(d.list_tri, d.n_list, np.int32),
             depth=int(d.tree_depth), nc=arr(d.tri_nc, nt * 3, np.float64).reshape(nt, 3),
-            verts=arr(d.tri_verts, nt * 9, np.float64).reshape(nt, 9))
+            verts=arr(d.tri_verts, nt * 9, np.float64).reshape(nt, 9), col=arr(d.tri_col, nt * 3, np.float64).reshape(nt, 3),
+            tri_tex=arr(d.tri_tex, nt, np.int32), tri_ts=arr(d.tri_ts, nt * 6, np.float64).reshape(nt, 6))
 
 
 def tonemap(rgb):

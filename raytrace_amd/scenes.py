@@ -4,7 +4,9 @@ and no assets, and there is no network, so these stand in for the demo / Bunny /
 Sponza / Lucy configurations at the same primitive counts.
 
 A scene is a dict:
-    meshes  : list of {verts (n,9) float64, lig (3,), col (3,), type, [tri_cols (n,3)]}
+    meshes  : list of {verts (n,9) float64, lig (3,), col (3,), type, [tri_cols (n,3)],
+                       [tri_tex (n,) int32 image index or -1, tri_ts (n,6) texture coordinates]}
+    textures: optional list of uint8 [rows, cols, 3] BGR images
     spheres : list of {rad, pos (3,), lig (3,), col (3,), type}
     camera  : {o (3,), d (3,)}      sizex (rows), sizey (columns), name
 Everything is generated with numpy's legacy MT19937 RandomState, which is stable across numpy
@@ -342,6 +344,53 @@ def deep_tree(levels=36, seed=4, size=1000.0, per=6, clutter=1500):
             "camera": {"o": np.array([0.3 * size, 0.3 * size, 2.2 * size]), "d": np.array([-0.1, -0.1, -1.0])}, "sizex": 48, "sizey": 64}
 
 
+def _grid_uv(nu, nv, reps=1.0, off=(0.0, 0.0)):
+    """Texture coordinates (ts[0..2].xy per triangle) matching grid(): (u, v) of each corner times `reps` plus `off`."""
+    u = np.linspace(0.0, 1.0, nu + 1) * reps + off[0]
+    v = np.linspace(0.0, 1.0, nv + 1) * reps + off[1]
+    U, Vv = np.meshgrid(u, v, indexing="ij")
+    P = np.stack([U, Vv], -1)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    t1 = np.concatenate([a, b, c], axis=-1).reshape(-1, 6)
+    t2 = np.concatenate([a, c, d], axis=-1).reshape(-1, 6)
+    return np.concatenate([t1, t2], axis=0)
+
+
+def test_images(seed=0):
+    """Three small BGR images of different, non-square sizes (the reference's lookup transposes a non-square image,
+    polygon.h:34 against opencvlib.cpp:19-29): a checker board, a colour ramp and noise."""
+    rs = np.random.RandomState(seed)
+    r, c = np.meshgrid(np.arange(37), np.arange(53), indexing="ij")
+    checker = np.where((((r // 5) + (c // 7)) % 2)[..., None] == 0, np.array([230, 60, 40]), np.array([40, 200, 235])).astype(np.uint8)
+    r, c = np.meshgrid(np.arange(64), np.arange(24), indexing="ij")
+    ramp = np.stack([255 * r // 63, 255 * c // 23, 255 - 255 * r // 63], -1).astype(np.uint8)
+    noise = rs.randint(0, 256, (16, 16, 3)).astype(np.uint8)
+    return [checker, ramp, noise]
+
+
+def textured_room(sizex=48, sizey=64, seed=0):
+    """A small room whose floor, back wall and a tilted mirror panel carry images (Polygon::getcol with a texture,
+    polygon.h:73-89), beside an untextured wall and a glass blob; one emissive sphere.  Texture coordinates run
+    past 1 on the floor (the lookup wraps with %), all stay non-negative (a negative one is undefined in the reference)."""
+    tex = test_images(seed)
+    floor = grid((-40, 0, -40), (0, 0, 120), (120, 0, 0), 5, 4)
+    back = grid((-40, 0, -40), (120, 0, 0), (0, 80, 0), 3, 3)
+    left = grid((-40, 0, -40), (0, 80, 0), (0, 0, 120), 2, 2)
+    panel = translate(rotate(grid((-15, -15, 0), (30, 0, 0), (0, 30, 0), 2, 2), (10, 35, 0)), (45, 30, 0))
+    gl = blob((5, 12, 25), 10.0, 8, 10, seed=3, amp=0.2)
+    n_f, n_b, n_p = floor.shape[0], back.shape[0], panel.shape[0]
+    meshes = [
+        dict(_mesh(floor, (.6, .6, .6), DIFF), tri_tex=np.zeros(n_f, np.int32), tri_ts=_grid_uv(5, 4, reps=2.5, off=(0.13, 0.4))),
+        dict(_mesh(back, (.6, .6, .6), DIFF), tri_tex=np.where(np.arange(n_b) % 5 == 4, -1, 1).astype(np.int32), tri_ts=_grid_uv(3, 3)),
+        _mesh(left, (.75, .25, .25), DIFF),
+        dict(_mesh(panel, (.9, .9, .9), SPEC), tri_tex=np.full(n_p, 2, np.int32), tri_ts=_grid_uv(2, 2, reps=0.999)),
+        _mesh(gl, (.999, .999, .999), REFR),
+    ]
+    return {"name": "textured_room", "meshes": meshes, "textures": tex,
+            "spheres": [_sphere(25, (20, 120, 40), (12, 12, 12), (0, 0, 0), DIFF)],
+            "camera": {"o": np.array([20, 56, 190.0]), "d": np.array([0.0, -0.15, -1.0])}, "sizex": sizex, "sizey": sizey}  # (rays start 140 units along d)
+
+
 def transformed(scene, scale=1.0, shift=(0.0, 0.0, 0.0)):
     """The scene uniformly scaled about the origin, then translated (meshes, spheres and camera)."""
     shift = np.asarray(shift, np.float64)
@@ -360,21 +409,55 @@ def transformed(scene, scale=1.0, shift=(0.0, 0.0, 0.0)):
     return out
 
 
+def write_bmp24(path, bgr):
+    """A 24-bit BMP (bottom-up rows padded to four bytes) from a uint8 [rows, cols, 3] BGR array."""
+    import struct
+    a = np.ascontiguousarray(bgr, np.uint8)
+    rows, cols = a.shape[:2]
+    stride = (cols * 3 + 3) & ~3
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", 54 + stride * rows, 0, 0, 54))
+        f.write(struct.pack("<IiiHHIIiiII", 40, cols, rows, 1, 24, 0, stride * rows, 2835, 2835, 0, 0))
+        for r in range(rows - 1, -1, -1):
+            f.write(a[r].tobytes() + b"\0" * (stride - cols * 3))
+
+
 def write_scene_files(scene, directory, c_samps=4, g_samps=4):
     """Write `scene` as a reference-format scene file (test.txt) plus one OBJ per mesh; returns the
-    path of test.txt.  Per-triangle colours are not representable without an MTL and are dropped."""
+    path of test.txt.  Textured meshes get `vt` lines, `v/t` faces, an MTL library with one material
+    per image (map_Kd for diffuse objects, map_Ks otherwise, object.cpp:113) and the images as BMP
+    files.  Per-triangle colours of untextured meshes are not written (the object's colour applies)."""
     import os
     os.makedirs(directory, exist_ok=True)
     tname = {DIFF: "DIFF", SPEC: "SPEC", REFR: "REFR"}
+    for k, t in enumerate(scene.get("textures", [])):
+        write_bmp24(os.path.join(directory, f"tex{k}.bmp"), t)
     lines = [str(len(scene["meshes"]))]
     for i, m in enumerate(scene["meshes"]):
         v = m["verts"].reshape(-1, 3)
+        tt = m.get("tri_tex")
         with open(os.path.join(directory, f"mesh{i}.obj"), "w") as f:
             f.write("# generated\n")
+            if tt is not None:
+                with open(os.path.join(directory, f"mesh{i}.mtl"), "w") as fm:
+                    for k in sorted(set(int(x) for x in tt if x >= 0)):
+                        fm.write(f"newmtl img{k}\n{'map_Kd' if m['type'] == DIFF else 'map_Ks'} tex{k}.bmp\n")
+                f.write(f"mtllib mesh{i}.mtl\n")
             for p in v:
                 f.write("v %s %s %s\n" % (repr(float(p[0])), repr(float(p[1])), repr(float(p[2]))))
+            if tt is not None:
+                for p in np.asarray(m["tri_ts"], np.float64).reshape(-1, 2):
+                    f.write("vt %s %s\n" % (repr(float(p[0])), repr(float(p[1]))))
+            cur = None
             for t in range(v.shape[0] // 3):
-                f.write(f"f {3 * t + 1} {3 * t + 2} {3 * t + 3}\n")
+                if tt is None:
+                    f.write(f"f {3 * t + 1} {3 * t + 2} {3 * t + 3}\n")
+                    continue
+                want = int(tt[t])
+                if want != cur:
+                    f.write(f"usemtl img{want}\n" if want >= 0 else "usemtl none\n")  # an unknown name selects the object's colour
+                    cur = want
+                f.write(f"f {3 * t + 1}/{3 * t + 1} {3 * t + 2}/{3 * t + 2} {3 * t + 3}/{3 * t + 3}\n")
         lig, col = m["lig"], m["col"]
         lines.append(f"mesh{i}.obj 1 0 0 0 0 0 0 " + " ".join(repr(float(x)) for x in list(lig) + list(col)) + " " + tname[m["type"]])
     lines.append(str(len(scene["spheres"])))

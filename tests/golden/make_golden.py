@@ -13,6 +13,7 @@ Each .npz holds inputs (scene arrays, rays, points) and the reference's outputs 
     sph_*       Sphere::intersect per (sphere, ray)
     aabb_*      KdTreeNode::check_aabb for explicit (box, ray) pairs
     primary_*   Ray(cam.o + d * 140, d.norm()) as g++ evaluates it (raytrace.cpp:203)
+    getcol_*    Polygon::getcol(u, v) of textured and plain triangles (polygon.h:73-89), images included as data
 Nothing of the reference's source text is stored, only numbers.
 """
 import os
@@ -70,6 +71,12 @@ def scene_arrays(sc):
         out[f"m{i}_type"] = np.int32(m["type"])
         if "tri_cols" in m:
             out[f"m{i}_tri_cols"] = m["tri_cols"]
+        if m.get("tri_tex") is not None:
+            out[f"m{i}_tri_tex"] = np.asarray(m["tri_tex"], np.int32)
+            out[f"m{i}_tri_ts"] = np.asarray(m["tri_ts"], np.float64)
+    out["n_textures"] = np.int32(len(sc.get("textures", [])))
+    for k, t in enumerate(sc.get("textures", [])):
+        out[f"tex{k}"] = np.asarray(t, np.uint8)
     sp = sc["spheres"]
     out["sph_rad"] = np.array([s["rad"] for s in sp], np.float64)
     out["sph_pos"] = np.array([s["pos"] for s in sp], np.float64).reshape(-1, 3)
@@ -111,6 +118,15 @@ def make(name, sc, center, spread, n_rays):
             tout.append(ref.poly_intersect(g, r))
         fx["tri_rays"] = np.array(tr)
         fx["tri_tuv"] = np.array(tout)
+    if sc.get("textures"):  # getcol for (u, v) inside the triangle, on every triangle (textured or not)
+        gid = np.repeat(np.arange(ntri, dtype=np.int32), 6)
+        u = rs.uniform(0, 1, len(gid))
+        v = rs.uniform(0, 1, len(gid)) * (1 - u)
+        u[::6], v[::6] = 0.0, 0.0  # the corners and an edge point
+        u[1::6], v[1::6] = 1.0, 0.0
+        u[2::6], v[2::6] = 0.0, 1.0
+        fx["getcol_gid"], fx["getcol_uv"] = gid, np.stack([u, v], 1)
+        fx["getcol"] = np.array([ref.poly_getcol(g, a, b) for g, a, b in zip(gid, u, v)])
     if len(sc["spheres"]):
         ns = len(sc["spheres"])
         si = rs.randint(0, ns, 200).astype(np.int32)
@@ -163,5 +179,6 @@ if __name__ == "__main__":
     make("cornell", scenes.cornell_demo(), np.array([50, 40, 80.0]), 40.0, 1500)
     make("bunny2k", scenes.bunny_class(2000), np.array([50, 30, 80.0]), 50.0, 1500)
     make("sponza12k", scenes.sponza_class(12000, detail=0.12), np.array([50, 40, 130.0]), 60.0, 1000)
+    make("texroom", scenes.textured_room(), np.array([20, 30, 20.0]), 50.0, 1000)
     make_aabb()
     make_primary()

@@ -31,6 +31,9 @@ def test_oracle_tree_and_queries_match_reference(po, name):
     if "sph_idx" in fx:
         for i, r, t in zip(fx["sph_idx"], fx["sph_rays"], fx["sph_t"]):
             assert orc.sph_intersect(i, r) == t
+    if "getcol" in fx:  # Polygon::getcol with and without an image (polygon.h:73-89)
+        for g, uv, c in zip(fx["getcol_gid"], fx["getcol_uv"], fx["getcol"]):
+            assert np.array_equal(orc.tri_getcol(g, uv[0], uv[1]), c), (g, uv)
 
 
 def test_getn_is_the_face_normal(po):
@@ -50,6 +53,14 @@ def test_host_builder_matches_reference_tree(ra, name):
         assert np.array_equal(t[k], fx["tree_" + k]), k
     if "nc_gid" in fx:
         assert np.array_equal(t["nc"][fx["nc_gid"]], fx["nc"])
+    if "getcol" in fx:  # images and texture coordinates arrive in the description unchanged
+        sc = scene_from_fixture(fx)
+        for a, b in zip(hs.textures(), sc["textures"]):
+            assert np.array_equal(a, b)
+        tt = np.concatenate([m.get("tri_tex", np.full(len(m["verts"]), -1, np.int32)) for m in sc["meshes"]])
+        assert np.array_equal(t["tri_tex"], tt)
+        ts = np.concatenate([m.get("tri_ts", np.zeros((len(m["verts"]), 6))) for m in sc["meshes"]])
+        assert np.array_equal(t["tri_ts"][tt >= 0], ts[tt >= 0])
 
 
 def test_oracle_check_aabb_matches_reference(po):

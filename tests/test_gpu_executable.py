@@ -1,9 +1,11 @@
 """The raytrace_hip executable (the reference's main, raytrace.cpp:97-248, on top of the two C ABIs):
-scene file in the reference's format in, BMP out."""
+scene file in the reference's format in, BMP out -- compared byte for byte (within +-1 per channel, the
+parity bar) with drawPixel (raytrace.cpp:33-39) of the oracle's frame of the same scene."""
 import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -11,18 +13,39 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_executable_renders_a_scene_file(tmp_path):
+def _read_bmp(path):
+    data = open(path, "rb").read()
+    assert data[:2] == b"BM"
+    off = int.from_bytes(data[10:14], "little")
+    cols, rows = int.from_bytes(data[18:22], "little"), int.from_bytes(data[22:26], "little")
+    stride = (cols * 3 + 3) & ~3
+    a = np.frombuffer(data, np.uint8, stride * rows, off).reshape(rows, stride)[:, :cols * 3].reshape(rows, cols, 3)
+    return a[::-1]  # stored bottom-up
+
+
+@pytest.mark.parametrize("which", ["cornell", "textured"])
+def test_executable_output_matches_oracle(po, tmp_path, which):
     sys.path.insert(0, ROOT)
     from raytrace_amd import scenes
     exe = os.path.join(ROOT, "raytrace_amd", "bin", "raytrace_hip")
     assert os.path.exists(exe), f"{exe} is missing: run make -C raytrace_amd/csrc"
     sizex, sizey = 96, 128
-    scene_file = scenes.write_scene_files(scenes.cornell_demo(sizex, sizey), str(tmp_path), c_samps=1, g_samps=1)
+    sc = scenes.cornell_demo(sizex, sizey) if which == "cornell" else scenes.textured_room(sizex, sizey)
+    for m in sc["meshes"]:
+        m.pop("tri_cols", None)  # not representable in the scene file
+    scene_file = scenes.write_scene_files(sc, str(tmp_path), c_samps=1, g_samps=2)
     out = str(tmp_path / "o.bmp")
-    r = subprocess.run([exe, scene_file, "-o", out, "--samps", "1", "--depth", "4", "--rr", "0"], capture_output=True, text=True, timeout=100)
+    r = subprocess.run([exe, scene_file, "-o", out, "--depth", "4", "--rr", "0", "--seed", "5", "--tile", "40"], capture_output=True, text=True, timeout=100)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "1020 triangles, 9 spheres" in r.stdout
-    data = open(out, "rb").read()
-    assert data[:2] == b"BM" and len(data) >= 54 + sizex * sizey * 3
-    # not a black frame: the Cornell demo is lit
-    assert max(data[54:]) > 100
+    assert f"{scenes.num_tris(sc)} triangles, {len(sc['spheres'])} spheres" in r.stdout
+    img = _read_bmp(out)
+    assert img.shape == (sizex, sizey, 3)
+    orc = po.OracleScene(sc)
+    kw = dict(samps=2, rr_depth=4, rr_mode=0, split_depth=2, hard_depth=100000, jitter=1, seed=5)  # g_samps of the scene file, the flags above
+    orgb, _, ost = orc.render_tile(po.make_camera(sc["camera"]["o"], sc["camera"]["d"], sizex, sizey), po.make_params(**kw), 0, 0, sizex, sizey, nthreads=8)
+    want = po.draw_pixels(orgb)
+    close = (np.abs(img.astype(np.int32) - want.astype(np.int32)).max(axis=-1) <= 1).mean()
+    assert close >= 0.999, close
+    assert img.max() > 100  # a lit frame
+    rays = int(r.stdout.strip().splitlines()[-1].split()[0])
+    assert abs(rays - ost["rays"]) <= 1e-3 * ost["rays"] + 2

@@ -152,3 +152,84 @@ def test_scene_generators_hit_their_triangle_counts():
     assert len(s["spheres"]) == 10000 and not s["meshes"]
     a, b = scenes.sponza_class(30000, detail=0.25), scenes.sponza_class(30000, detail=0.25)
     assert all(np.array_equal(x["verts"], y["verts"]) for x, y in zip(a["meshes"], b["meshes"]))  # deterministic
+
+
+def test_obj_with_materials_textures_and_images(ra, tmp_path):
+    """OBJ + MTL + image files: vt lines, v/t faces, usemtl, map_Kd (object.cpp:44-49,112-119,164-171,254,280) and
+    the image reader standing in for cv::imread (BMP and binary PPM, top row first, BGR)."""
+    from raytrace_amd import scenes
+    sc = scenes.textured_room()
+    path = scenes.write_scene_files(sc, str(tmp_path))
+    hs = ra.HostScene.from_file(path)
+    want = ra.HostScene(sc).tree_arrays()
+    got = hs.tree_arrays()
+    assert np.array_equal(got["verts"], want["verts"])
+    assert np.array_equal(got["tri_tex"] >= 0, want["tri_tex"] >= 0)
+    assert np.array_equal(got["tri_ts"][got["tri_tex"] >= 0], want["tri_ts"][want["tri_tex"] >= 0])
+    imgs, ref_imgs = hs.textures(), sc["textures"]
+    for g, w in zip(got["tri_tex"], want["tri_tex"]):  # images are numbered in loading order: compare contents
+        if w >= 0:
+            assert np.array_equal(imgs[g], ref_imgs[w])
+    # binary PPM (RGB in the file, BGR in memory), with a comment line
+    img = ref_imgs[1]
+    with open(tmp_path / "a.ppm", "wb") as f:
+        f.write(b"P6\n# a comment\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img[..., ::-1].tobytes())
+    k = hs.load_texture_file(tmp_path / "a.ppm")
+    assert np.array_equal(hs.textures()[k], img)
+    with pytest.raises(ra.capi.RtError, match="image"):
+        hs.load_texture_file(tmp_path / "missing.bmp")
+    # a material whose image is missing stays untextured (opencvlib.cpp:13-14) and keeps its Kd colour
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 0.1 0.2 0.3\nmap_Kd nothere.bmp\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n")
+    h2 = ra.HostScene()
+    h2.add_obj_file(tmp_path / "m.obj", 1, (0, 0, 0), (0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    h2.build()
+    t2 = h2.tree_arrays()
+    assert t2["tri_tex"][0] == -1 and np.array_equal(t2["col"][0], [0.1, 0.2, 0.3])
+
+
+def test_texture_resize_follows_the_object_scale(ra, tmp_path):
+    """loadImage resizes the image by the object's scale (opencvlib.cpp:16-20): sizes are truncated products, equal
+    sizes copy, a constant image stays constant, and a 2x enlargement of a ramp stays monotonic between its ends.
+    (The interpolation arithmetic itself has no OpenCV here to be compared with.)"""
+    from raytrace_amd import scenes
+    ramp = np.zeros((8, 10, 3), np.uint8)
+    ramp[..., 0] = np.arange(10)[None, :] * 20
+    ramp[..., 1] = 77
+    ramp[..., 2] = np.arange(8)[:, None] * 30
+    scenes.write_bmp24(tmp_path / "r.bmp", ramp)
+    hs = ra.HostScene()
+    a = hs.load_texture_file(tmp_path / "r.bmp", 1.0)
+    b = hs.load_texture_file(tmp_path / "r.bmp", 2.0)
+    c = hs.load_texture_file(tmp_path / "r.bmp", 0.55)
+    hs.build()
+    t = hs.textures()
+    assert np.array_equal(t[a], ramp)
+    assert t[b].shape == (16, 20, 3) and t[c].shape == (4, 5, 3)
+    assert (t[b][..., 1] == 77).all() and (t[c][..., 1] == 77).all()
+    assert (np.diff(t[b][..., 0].astype(int), axis=1) >= 0).all() and t[b][0, 0, 0] == 0 and t[b][0, -1, 0] == 180
+    assert (np.diff(t[b][..., 2].astype(int), axis=0) >= 0).all() and t[b][-1, 0, 2] == 210
+
+
+def test_obj_reader_extensions_are_opt_in(ra, tmp_path):
+    """Quads and negative indices: by default the 4th vertex is dropped and a negative index is an error, as in the
+    reference (object.cpp:186-257,271-277); the flags of rth_add_obj_file_ex triangulate and resolve them."""
+    (tmp_path / "q.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt .5 2\n"
+                                    "f 1/1 2/2 3/3 4/4 5/5\nf -5/-5 -4/-4 -3/-3\n")
+    args = (1, (0, 0, 0), (0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    hs = ra.HostScene()
+    with pytest.raises(ra.capi.RtError, match="Error face"):
+        hs.add_obj_file(tmp_path / "q.obj", *args)
+    hs = ra.HostScene()
+    hs.add_obj_file(tmp_path / "q.obj", *args, flags=ra.capi.RTH_OBJ_NEGATIVE)
+    hs.build()
+    assert hs.num_tris == 2  # the pentagon's first three vertices, and the relative face
+    assert np.array_equal(hs.tree_arrays()["verts"][1].reshape(3, 3), [[0, 0, 0], [1, 0, 0], [1, 1, 0]])
+    hs = ra.HostScene()
+    hs.add_obj_file(tmp_path / "q.obj", *args, flags=ra.capi.RTH_OBJ_NEGATIVE | ra.capi.RTH_OBJ_TRIANGULATE)
+    hs.build()
+    t = hs.tree_arrays()
+    assert hs.num_tris == 4  # a fan of three, and the relative face
+    assert np.array_equal(t["verts"][:3].reshape(3, 3, 3)[:, 0], np.zeros((3, 3)))
+    assert np.array_equal(t["verts"][2].reshape(3, 3), [[0, 0, 0], [0, 1, 0], [0.5, 2, 0]])
+    assert np.array_equal(t["tri_ts"][2], [0, 0, 0, 1, .5, 2])

@@ -62,3 +62,24 @@ def test_degenerate_inputs(ref):
         got, want = orc.trace(rays), rf.trace(rays)
         for x, y in zip(got[:4], want):
             assert np.array_equal(x, y)
+
+
+def test_textured_getcol_matches_reference(ref):
+    """Polygon::getcol / GetImageData (polygon.h:30-35,73-89) on the reference's own Polygon objects built with its
+    constructor's texture arguments: the transposed lookup, the wrap-around past 1, BGR order, /256 and pow 2.2,
+    bit for bit, for coordinates that stay inside the image."""
+    from raytrace_amd import scenes
+    for seed in (0, 1):
+        sc = scenes.textured_room(seed=seed)
+        orc, rf = ref.OracleScene(sc), ref.RefScene(sc)
+        rs = np.random.RandomState(seed)
+        n = scenes.num_tris(sc)
+        seen = set()
+        for g in range(n):
+            for _ in range(8):
+                u = rs.uniform(0, 1)
+                v = rs.uniform(0, 1 - u)
+                a, b = orc.tri_getcol(g, u, v), rf.poly_getcol(g, u, v)
+                assert np.array_equal(a, b), (g, u, v)
+                seen.add(tuple(a))
+        assert len(seen) > 100  # many different texels were read
