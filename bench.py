@@ -140,6 +140,13 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+    else:
+        # one GPU runs the same program as N: a one-rank RCCL group (rendezvous through a file, no network) for the
+        # barrier and the reductions; its frame needs no exchange (tests/test_gpu_rccl.py drives the gather itself
+        # through a one-rank group)
+        import tempfile
+        store = os.path.join(tempfile.mkdtemp(prefix="rt_bench_pg_"), "store")
+        dist.init_process_group("nccl", init_method="file://" + store, rank=0, world_size=1, device_id=device)
 
     scene, mode = build_workload(args.workload, args.sizex, args.sizey)
     sizex, sizey = scene["sizex"], scene["sizey"]
@@ -152,9 +159,8 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(device)
+        dist.barrier()
+        torch.cuda.synchronize(device)
 
     def step(i, ev=None):
         fr.params.seed = 1 + i  # a fresh random stream every frame
@@ -180,9 +186,8 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     cnt = torch.tensor([st["rays"], st["node_visits"], st["tri_tests"], st["sph_tests"], st["tri_shades"]], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     rays_total = float(cnt[0].item())
 
@@ -251,7 +256,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+    dist.destroy_process_group()
     dev.close()
 
 

@@ -1,31 +1,57 @@
-// raytrace_hip -- the RayTrace program on top of the two C ABIs: read a scene file in the
+// raytrace_hip -- the RayTrace program on top of the C ABIs: read a scene file in the
 // reference's format, build the kd-tree on the host, upload the scene to every GPU, render
-// interleaved tiles (one host thread and one kernel launch per GPU), tone-map and write a BMP.
+// interleaved tiles (one host thread and one kernel launch per GPU), gather the GPUs' packed
+// shares on GPU 0 over RCCL, tone-map and write a BMP.
 //
 // It takes the place of the reference's main (raytrace.cpp:97-248): the scene-file grammar, the
-// camera, the per-pixel arithmetic and drawPixel are the reference's; the MPI row-band split and
-// the OpenCV window are gone (tiles are disjoint, output is headless).  This single-process
-// driver collects the GPUs' tile buffers with device-to-host copies; the one-process-per-GPU
-// driver that assembles the frame with an RCCL gather is raytrace_amd/frame.py.
+// camera, the per-pixel arithmetic and drawPixel are the reference's; the MPI row-band split with
+// its MPI_Isend / MPI_Recv exchange (raytrace.cpp:179, 211, 219-227) became disjoint tiles and one
+// grouped RCCL exchange (include/rt_gather.h), and the OpenCV window is gone (output is headless).
 //
 // usage: raytrace_hip [scene.txt] [-o output.bmp] [--samps N] [--depth N] [--rr 0|1] [--seed N]
-//                     [--gpus N] [--tile N]
+//                     [--gpus N] [--tile N] [--gather rccl|copy] [--obj-flags N]
+//   --gather copy   collects the shares with one device-to-host copy per GPU instead of the RCCL exchange
+//   --obj-flags     RTH_OBJ_* bits for the OBJ reader (1: triangulate polygons, 2: negative indices)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include "rt_gather.h"
 #include "rt_hip.h"
 #include "rt_host.h"
+
+namespace {
+// All GPU threads meet here before the exchange: a collective that one rank never joins would hang the others.
+struct Meet {
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0, round = 0, n = 0;
+    bool failed = false;
+    bool arrive(bool ok) { // returns true if every thread arrived without a failure
+        std::unique_lock<std::mutex> lk(mu);
+        if (!ok) failed = true;
+        const int my = round;
+        if (++waiting == n) { waiting = 0; round++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return round != my; });
+        return !failed;
+    }
+};
+} // namespace
 
 int main(int argc, char **argv) {
     std::string scene_path = "test.txt", out_path = "output.bmp"; // raytrace.cpp:106, 234
     int samps = -1, depth = 5, rr = 1, gpus = -1, tile = 64;
+    unsigned obj_flags = 0;
+    bool use_rccl = true;
     unsigned long long seed = 1;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -40,12 +66,14 @@ int main(int argc, char **argv) {
         else if (a == "--seed") seed = strtoull(next("--seed"), nullptr, 10);
         else if (a == "--gpus") gpus = atoi(next("--gpus"));
         else if (a == "--tile") tile = atoi(next("--tile"));
+        else if (a == "--gather") use_rccl = std::string(next("--gather")) != "copy";
+        else if (a == "--obj-flags") obj_flags = (unsigned)atoi(next("--obj-flags"));
         else scene_path = a;
     }
     const auto t0 = std::chrono::steady_clock::now();
     rth_scene *hs = rth_scene_new();
     rth_settings st;
-    if (rth_load_scene_file(hs, scene_path.c_str(), &st) < 0 || rth_build(hs) < 0) {
+    if (rth_load_scene_file_ex(hs, scene_path.c_str(), &st, obj_flags) < 0 || rth_build(hs) < 0) {
         fprintf(stderr, "%s\n", rth_last_error());
         return 1;
     }
@@ -71,42 +99,74 @@ int main(int argc, char **argv) {
     std::vector<rt_stats> stats((size_t)ndev);
     std::vector<int> status((size_t)ndev, 0);
     std::vector<std::string> errors((size_t)ndev);
+    // tile i belongs to GPU i mod ndev; a GPU's share is its tiles back to back
+    std::vector<std::vector<rt_tile>> share((size_t)ndev);
+    std::vector<uint64_t> counts((size_t)ndev, 0); // doubles per share
+    for (size_t i = 0; i < tiles.size(); i++) share[i % (size_t)ndev].push_back(tiles[i]);
+    uint64_t total = 0;
+    for (int g = 0; g < ndev; g++) {
+        for (const rt_tile &t : share[g]) counts[g] += (uint64_t)t.rows * t.cols * 3;
+        total += counts[g];
+    }
+    rt_gather *xg = nullptr;
+    if (use_rccl) { // raytrace.cpp:99-104: the group of ranks
+        std::vector<int32_t> devs((size_t)ndev);
+        for (int g = 0; g < ndev; g++) devs[g] = g;
+        if (rt_gather_create(ndev, devs.data(), &xg) < 0) { fprintf(stderr, "%s\n", rt_gather_last_error()); return 1; }
+    }
+    std::vector<double> gathered(use_rccl ? (size_t)total : 0); // all shares in rank order, as they arrive on GPU 0
+    std::vector<std::vector<double>> copied((size_t)ndev);       // --gather copy: one host buffer per GPU
+    Meet meet;
+    meet.n = ndev;
     std::vector<std::thread> workers;
     for (int g = 0; g < ndev; g++)
         workers.emplace_back([&, g]() {
             char info[512];
             if (rt_device_info(g, info, sizeof(info)) == 0) printf("%s\n", info); // raytrace.cpp:164
-            std::vector<rt_tile> mine;
-            for (size_t i = g; i < tiles.size(); i += (size_t)ndev) mine.push_back(tiles[i]);
-            if (mine.empty()) return;
-            size_t npix = 0;
-            for (const rt_tile &t : mine) npix += (size_t)t.rows * t.cols;
             rt_scene *ds = nullptr;
-            double *d_rgb = nullptr;
-            std::vector<double> packed(npix * 3);
+            double *d_rgb = nullptr, *d_all = nullptr;
             int rc = rt_upload_scene(g, desc, &ds);
-            if (rc == 0 && hipMalloc((void **)&d_rgb, npix * 3 * sizeof(double)) != hipSuccess) rc = RT_E_NOMEM;
-            if (rc == 0) rc = rt_render_tiles_device(ds, &cam, mine.data(), (int)mine.size(), &prm, d_rgb, nullptr, nullptr);
+            if (rc == 0 && hipMalloc((void **)&d_rgb, std::max<uint64_t>(counts[g], 1) * sizeof(double)) != hipSuccess) rc = RT_E_NOMEM;
+            if (rc == 0 && use_rccl && g == 0 && hipMalloc((void **)&d_all, total * sizeof(double)) != hipSuccess) rc = RT_E_NOMEM;
+            if (rc == 0 && !share[g].empty())
+                rc = rt_render_tiles_device(ds, &cam, share[g].data(), (int)share[g].size(), &prm, d_rgb, nullptr, nullptr);
             if (rc == 0) rc = rt_get_stats(ds, &stats[g]);
-            if (rc == 0 && hipMemcpy(packed.data(), d_rgb, npix * 3 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RT_E_DEVICE;
             if (rc != 0) { status[g] = rc; errors[g] = rt_last_error(); }
-            else {
-                size_t off = 0;
-                for (const rt_tile &t : mine)
-                    for (int r = 0; r < t.rows; r++) {
-                        memcpy(&frame[((size_t)(t.x0 + r) * st.sizey + t.y0) * 3], &packed[off], (size_t)t.cols * 3 * sizeof(double));
-                        off += (size_t)t.cols * 3;
-                    }
+            const bool all_ok = meet.arrive(rc == 0);
+            if (all_ok && use_rccl) { // raytrace.cpp:211, 219-227: every rank's share to rank 0
+                rc = rt_gather_shares(xg, g, d_rgb, d_all, counts.data(), nullptr);
+                if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = RT_E_DEVICE;
+                if (rc == 0 && g == 0 && hipMemcpy(gathered.data(), d_all, total * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RT_E_DEVICE;
+                if (rc != 0) { status[g] = rc; errors[g] = rc == RT_E_DEVICE && !*rt_gather_last_error() ? "HIP error after the exchange" : rt_gather_last_error(); }
+            } else if (all_ok) {
+                copied[g].resize((size_t)counts[g]);
+                if (counts[g] && hipMemcpy(copied[g].data(), d_rgb, counts[g] * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+                    status[g] = RT_E_DEVICE; errors[g] = "device-to-host copy failed";
+                }
             }
             if (d_rgb) (void)hipFree(d_rgb);
+            if (d_all) (void)hipFree(d_all);
             rt_free_scene(ds);
         });
     for (auto &w : workers) w.join();
-    unsigned long long rays = 0;
-    for (int g = 0; g < ndev; g++) {
+    if (xg) rt_gather_destroy(xg);
+    for (int g = 0; g < ndev; g++)
         if (status[g]) { fprintf(stderr, "GPU %d failed: %s\n", g, errors[g].c_str()); return 1; }
-        rays += stats[g].rays;
+    { // un-permute: rank order, tiles back to back, rows inside a tile
+        size_t off = 0;
+        for (int g = 0; g < ndev; g++) {
+            const double *src = use_rccl ? gathered.data() + off : copied[g].data();
+            size_t at = 0;
+            for (const rt_tile &t : share[g])
+                for (int r = 0; r < t.rows; r++) {
+                    memcpy(&frame[((size_t)(t.x0 + r) * st.sizey + t.y0) * 3], src + at, (size_t)t.cols * 3 * sizeof(double));
+                    at += (size_t)t.cols * 3;
+                }
+            off += (size_t)counts[g];
+        }
     }
+    unsigned long long rays = 0;
+    for (int g = 0; g < ndev; g++) rays += stats[g].rays;
     std::vector<uint8_t> bgr((size_t)st.sizex * st.sizey * 3);
     rth_tonemap(frame.data(), (size_t)st.sizex * st.sizey, bgr.data());
     printf("Save image to %s\n", out_path.c_str());

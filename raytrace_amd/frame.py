@@ -56,7 +56,10 @@ class FrameRenderer:
     world > 1, gathers all packed shares to rank 0, which scatters them into the full frame.
     """
 
-    def __init__(self, scene, cam, params, tile_rows=64, tile_cols=64, rank=0, world=1, device=None, want_ids=False):
+    def __init__(self, scene, cam, params, tile_rows=64, tile_cols=64, rank=0, world=1, device=None, want_ids=False,
+                 collective=None):
+        """collective: run the gather through torch.distributed (default: when there is more than one rank; with one
+        rank there is nothing to exchange, and a forced gather -- what the RCCL test does -- costs a copy of the frame)."""
         import torch
         self.torch = torch
         self.scene, self.cam, self.params = scene, cam, params
@@ -68,13 +71,16 @@ class FrameRenderer:
         self.my_tiles = self.shards[rank]
         self.counts = [tile_pixels(s) for s in self.shards]
         self.want_ids = want_ids
+        if collective is None:
+            collective = world > 1
+        self.collective = bool(collective)
         # every rank's share is padded to the largest share so that one equal-size gather works
         self.max_pix = max(self.counts)
         self.local = torch.zeros((self.max_pix, 3), dtype=torch.float64, device=self.device)
         self.local_ids = torch.zeros((self.max_pix,), dtype=torch.int32, device=self.device) if want_ids else None
         self.gathered = None
         self.gathered_ids = None
-        if world > 1 and rank == 0:
+        if self.collective and rank == 0:
             self.gathered = [torch.zeros_like(self.local) for _ in range(world)]
             if want_ids:
                 self.gathered_ids = [torch.zeros_like(self.local_ids) for _ in range(world)]
@@ -95,19 +101,19 @@ class FrameRenderer:
     def assemble(self):
         """Gather to rank 0 (one collective) and un-permute the tiles there. Returns the frame on rank 0."""
         torch = self.torch
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0)
             if self.want_ids:
                 dist.gather(self.local_ids, self.gathered_ids if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
-        parts = self.gathered if self.world > 1 else [self.local]
+        parts = self.gathered if self.collective else [self.local]
         flat = self.frame.view(-1, 3)
         for r in range(self.world):  # one index_copy per rank's share
             flat.index_copy_(0, self.dest[r], parts[r][: self.counts[r]])
         if self.want_ids:
-            idparts = self.gathered_ids if self.world > 1 else [self.local_ids]
+            idparts = self.gathered_ids if self.collective else [self.local_ids]
             flat_ids = self.ids.view(-1)
             for r in range(self.world):
                 flat_ids.index_copy_(0, self.dest[r], idparts[r][: self.counts[r]])

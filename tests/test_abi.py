@@ -30,6 +30,17 @@ def test_device_library_exports_every_declared_symbol(ra):
     assert sorted(ra.capi.DEVICE_SYMBOLS) == names
 
 
+def test_gather_library_exports_every_declared_symbol():
+    """librt_rccl.so (it links librccl, so it is inspected, not loaded into this process)."""
+    import subprocess
+    names = declared("rt_gather.h", "rt_gather_")
+    assert len(names) == 4
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "raytrace_amd", "lib", "librt_rccl.so")], text=True)
+    have = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    for n in names:
+        assert n in have, n
+
+
 def test_struct_layouts_match_header(ra, tmp_path):
     """ctypes mirrors against what the C compiler makes of include/rt_hip.h and rt_host.h."""
     import subprocess
