@@ -138,9 +138,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    pg_mode = os.environ.get("RT_BENCH_PG", "early")  # experiment knob: early | late | none (one rank only)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
-    else:
+    elif pg_mode == "early":
         # one GPU runs the same program as N: a one-rank RCCL group (rendezvous through a file, no network) for the
         # barrier and the reductions; its frame needs no exchange (tests/test_gpu_rccl.py drives the gather itself
         # through a one-rank group)
@@ -156,11 +157,17 @@ def main():
     pkw = dict(samps=args.samps, rr_depth=mode["rr_depth"], rr_mode=mode["rr_mode"], split_depth=2, hard_depth=64, jitter=1, seed=1)
     prm = ra.capi.make_params(**pkw)
     fr = frame.FrameRenderer(dev, cam, prm, args.tile, args.tile, rank=rank, world=world, device=device)
+    if world == 1 and pg_mode == "late":
+        import tempfile
+        store = os.path.join(tempfile.mkdtemp(prefix="rt_bench_pg_"), "store")
+        dist.init_process_group("nccl", init_method="file://" + store, rank=0, world_size=1, device_id=device)
+    have_pg = dist.is_initialized()
 
     def sync_all():
         torch.cuda.synchronize(device)
-        dist.barrier()
-        torch.cuda.synchronize(device)
+        if have_pg:
+            dist.barrier()
+            torch.cuda.synchronize(device)
 
     def step(i, ev=None):
         fr.params.seed = 1 + i  # a fresh random stream every frame
@@ -186,8 +193,9 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     cnt = torch.tensor([st["rays"], st["node_visits"], st["tri_tests"], st["sph_tests"], st["tri_shades"]], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    if have_pg:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     rays_total = float(cnt[0].item())
 
@@ -256,7 +264,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-    dist.destroy_process_group()
+    if have_pg:
+        dist.destroy_process_group()
     dev.close()
 
 

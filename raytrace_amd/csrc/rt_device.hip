@@ -172,18 +172,13 @@ struct __attribute__((aligned(16))) SphGeom { double px, py, pz, rad; };
 struct __attribute__((aligned(16))) SphShade { double lig[3], col[3]; int type, pad0; double pad1; };
 static_assert(sizeof(SphShade) == 64, "SphShade must be 64 bytes");
 
+// What the traversal steps need of the scene: passed to the kernel by value, i.e. held in scalar registers for the
+// kernel's whole life.  What only the shade step needs is in ColdArgs.
 struct DevScene {
     const char *pool; // nodes + lists, cull records, triangles
-    const TriShade *tshade;
     const uint2 *tlist; // per triangle (device position): first list position of its own list, its own list position
-    const SphGeom *sph;
-    const SphShade *sshade;
-    const unsigned char *tex; // texture block (see TexTri), NULL without textures
     unsigned *ovf;  // overflow stack [ovf_depth][n_slots]
     double *lstate; // per-slot state kept in HBM [LS_WORDS][n_slots]
-    double cen[3]; // centre of the scene's vertex box
-    double reach;  // its summed half extents + the scene's longest triangle edge
-    double absn;   // |centre|_1 + summed half extents
     unsigned g_list; // granule of node 0's list record
     unsigned g_sphc; // granule of the sphere hierarchy's first cull record (the triangles' records lie below it)
     unsigned g_sph;  // granule of sphere 0's copy in the pool (two granules per sphere); tri items from here on are spheres
@@ -210,6 +205,35 @@ struct DevTile {
     int blk_cols;      // 8x8 blocks per block-row
 };
 
+// Everything only the shade step reads (camera, integrator controls, shading records, the launch's work list and
+// output buffers).  It lives in device memory and the kernel gets a pointer: passed by value these ~90 words would
+// sit in scalar registers through the traversal steps, which already spill theirs.
+struct ColdArgs {
+    DevCamera cam;
+    rt_params P;
+    const TriShade *tshade;
+    const SphGeom *sph;
+    const SphShade *sshade;
+    const unsigned char *tex; // texture block (see TexTri), NULL without textures
+    double cen[3]; // centre of the scene's vertex box
+    double reach;  // its summed half extents + the scene's longest triangle edge
+    double absn;   // |centre|_1 + summed half extents
+    const DevTile *tiles;
+    const int *blk_tile;
+    unsigned *counter;
+    double *rgb;
+    int *prim;
+    double *subbuf;
+    unsigned *subcnt;
+    const double *rays;
+    int *tri_id;
+    double *tri_t;
+    int *sph_id;
+    double *sph_t;
+    unsigned n_work;
+    int n_tiles;
+};
+
 struct d3 { double x, y, z; };
 __device__ __forceinline__ d3 mk(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ d3 operator+(d3 a, d3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -222,6 +246,22 @@ __device__ __forceinline__ d3 cross(d3 a, d3 b) {
 }
 __device__ __forceinline__ d3 normv(d3 a) { return a * (1 / sqrt(a.x * a.x + a.y * a.y + a.z * a.z)); } // point.h:49
 __device__ __forceinline__ d3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+
+// A pointer read from memory has no known address space, and the compiler then uses generic-address loads and stores
+// for it (which also count as LDS traffic and order against every LDS access).  All such pointers here point to
+// device memory: tell the compiler so.
+template <class T>
+__device__ __forceinline__ T *as_global(T *p) {
+#ifdef __HIP_DEVICE_COMPILE__
+    typedef __attribute__((address_space(1))) T *global_ptr;
+    // (the value goes through an opaque no-op so that the cast into the global address space is not folded away)
+    unsigned long long v = (unsigned long long)p; // (wavefront-uniform wherever this is used: it stays in scalar registers)
+    asm("" : "+s"(v));
+    return (T *)(global_ptr)v;
+#else
+    return p;
+#endif
+}
 
 // drand48 recurrence; every path restarts it from a hashed state
 __device__ __forceinline__ double rng_next(unsigned long long &x) {
@@ -315,11 +355,11 @@ __device__ __forceinline__ bool slab_hit(const double (&lo0)[3], const double (&
 }
 
 // sphere.cpp:3-14 over sphere.h:13-21: scan from the last sphere down, strict <
-__device__ __forceinline__ void trace_spheres(const DevScene &S, d3 o, d3 d, double &ts, int &ids) {
+__device__ __forceinline__ void trace_spheres(const SphGeom *sph, int n_sph, d3 o, d3 d, double &ts, int &ids) {
     ts = 1e20;
     ids = -1;
-    for (int i = S.n_sph; i--;) {
-        const SphGeom g = S.sph[i];
+    for (int i = n_sph; i--;) {
+        const SphGeom g = sph[i];
         const d3 op = mk(g.px, g.py, g.pz) - o;
         const double b = dot(op, d);
         double det = b * b - dot(op, op) + g.rad * g.rad;
@@ -477,11 +517,10 @@ __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30
 // SLOTS, LDS_STACK: see KernelCfg.
 // TEX = true: the scene has textured triangles (an instance of its own, like SPH).
 template <bool TRACE, bool SPH, bool TEX, int SLOTS, int LDS_STACK>
-__global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCamera cam, rt_params P, const DevTile *tiles, int n_tiles,
-                                                             unsigned n_work, unsigned *counter, double *rgb, int *prim,
-                                                             const double *rays, int *tri_id, double *tri_t, int *sph_id,
-                                                             double *sph_t, unsigned long long *gstats, double *subbuf,
-                                                             unsigned *subcnt, const int *blk_tile) {
+#ifndef RT_KALIGN
+#define RT_KALIGN 256
+#endif
+__global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIGN))) void k_main(DevScene S, const ColdArgs *__restrict__ cold, unsigned long long *gstats) {
     __shared__ double2 sA[SLOTS]; // origin x, y
     __shared__ double2 sB[SLOTS]; // origin z, 1/direction x
     __shared__ double2 sC[SLOTS]; // 1/direction y, z
@@ -498,10 +537,6 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     static_assert(SLOTS >= WAVE && SLOTS <= 256, "a slot index is kept in 8 bits");
     static_assert((LDS_STACK & (LDS_STACK - 1)) == 0 && REFILL >= 1 && REFILL - 1 <= LDS_STACK, "the refilled levels but the first go to the ring");
     static_assert(SLOT_STRIDE % 32 == 0 && SLOT_STRIDE >= SLOTS, "a wavefront's 4-byte columns of the HBM state start on a cache line");
-#ifdef RT_LDS_PAD // occupancy experiments: unused LDS that the compiler cannot drop
-    __shared__ unsigned lds_pad[RT_LDS_PAD / 4];
-    if (n_work == 0xFFFFFFFFu) { lds_pad[threadIdx.x] = n_work; __syncthreads(); n_work = lds_pad[threadIdx.x ^ 1]; }
-#endif
     const int lane = threadIdx.x;
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     auto qindex = [](int kind, int i) __attribute__((always_inline)) { return (kind >> 1) * SLOTS + ((kind & 1) ? SLOTS - 1 - i : i); };
@@ -516,9 +551,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     int q0 = 0, q1 = 0, q2 = 0, q3 = SLOTS; // entries on the four stacks
     // pieces of work taken from the counter and not handed to a slot yet: first piece, count (in LDS because only
     // the lanes of a shade step see an update)
-    // (volatile: one lane writes what the others read; the compiler must not keep a lane's old value)
-    __shared__ volatile unsigned sStash[2];
-    if (lane == 0) { sStash[0] = 0u; sStash[1] = 0u; }
+    // (one lane writes what the others read, so the compiler must not keep a lane's old value: relaxed atomic
+    // accesses -- a `volatile` array here is accessed through generic-address instructions, and one of those in
+    // flight makes the compiler put a full wait before every LDS read that follows)
+    __shared__ unsigned sStash[2];
+    auto stash_get = [&](int i) __attribute__((always_inline)) { return __hip_atomic_load(&sStash[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto stash_put = [&](int i, unsigned v) __attribute__((always_inline)) { __hip_atomic_store(&sStash[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    if (lane == 0) { stash_put(0, 0u); stash_put(1, 0u); }
     // work counters: wavefront-uniform 32-bit sums of lane counts in scalar registers, flushed to
     // the 64-bit totals in HBM long before they can overflow; only the own-list lengths need a
     // per-lane sum
@@ -543,7 +582,6 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
     };
 #define RT_SCOUNT(c, n) (c) += (unsigned)(n)
 
-    const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
 
 #ifdef RT_PROFILE
     unsigned long long p_vote = 0, p_body[4] = {0, 0, 0, 0}, p_tail = 0, p_n[4] = {0, 0, 0, 0}, p_tri[4] = {0, 0, 0, 0};
@@ -610,6 +648,12 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         unsigned push_item = 0; // item to push before that (0 = none; the root is never pushed)
         bool done = false;      // the slot found no more work
         RT_TICK(tk1);
+#ifdef RT_WAIT_TOP
+        // Nothing of the previous step is still in flight when a step issues its loads: otherwise the compiler, which
+        // cannot know which kind of step ran last, guards the first reuse of any register a conditional load of ANY
+        // step may still be writing with a full wait -- in the middle of this step's own loads.
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+#endif
 
         if (pick == K_NODE) {
             const bool refill = run && cur == IT_REFILL;
@@ -960,6 +1004,19 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
         } else {
             bool ev_ray = false, ev_shade = false, ev_scan = false;
             if (run) { // ---- traversal finished (or nothing started yet)
+                // the launch's cold arguments, read here and nowhere else
+                const ColdArgs &C = *cold;
+                const rt_params &P = C.P;
+                const DevCamera &cam = C.cam;
+                const int sizex = cam.sizex, sizey = cam.sizey, samps = P.samps;
+                const unsigned n_work = C.n_work;
+                unsigned *const counter = as_global(C.counter);
+                double *const rgb = as_global(C.rgb), *const subbuf = as_global(C.subbuf);
+                int *const prim = C.prim ? as_global(C.prim) : nullptr;
+                unsigned *const subcnt = as_global(C.subcnt);
+                const TriShade *const c_tshade = as_global(C.tshade);
+                const SphGeom *const c_sph = as_global(C.sph);
+                const SphShade *const c_sshade = as_global(C.sshade);
                 bool go_on = false, need_primary = false, need_work = false;
                 d3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
                 const unsigned long long wp = (unsigned long long)__double_as_longlong(ls[LS_PST * lss]);
@@ -981,28 +1038,28 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     int ids;
                     const long long wsi = SPH ? __double_as_longlong(ls[LS_SI * lss]) : -2ll;
                     if (wsi != -2ll) { ts = ls[LS_ST * lss]; ids = (int)wsi; } // found through the hierarchy
-                    else { trace_spheres(S, o, d, ts, ids); ev_scan = true; }
+                    else { trace_spheres(c_sph, S.n_sph, o, d, ts, ids); ev_scan = true; }
                     const bool fo = to < 1e10, fs = ts < 1e10;
                     if (TRACE) {
                         if (fo && !(ts < to)) ev_shade = true;
-                        tri_id[outk] = fo ? S.tshade[tpos].gid : -1;
-                        tri_t[outk] = to;
-                        sph_id[outk] = fs ? ids : -1;
-                        sph_t[outk] = ts;
+                        as_global(C.tri_id)[outk] = fo ? c_tshade[tpos].gid : -1;
+                        as_global(C.tri_t)[outk] = to;
+                        as_global(C.sph_id)[outk] = fs ? ids : -1;
+                        as_global(C.sph_t)[outk] = ts;
                         need_work = true;
                     } else if (fo || fs) { // raytrace.cpp:48-67
                         d3 x, n, f, lig;
                         int type;
                         d3 thr = mk(ls[LS_THR * lss], ls[(LS_THR + 1) * lss], ls[(LS_THR + 2) * lss]);
                         if (ts < to || !fo) {
-                            const SphGeom g = S.sph[ids];
-                            const SphShade sh = S.sshade[ids];
+                            const SphGeom g = c_sph[ids];
+                            const SphShade sh = c_sshade[ids];
                             x = o + d * ts;
                             n = normv(x - mk(g.px, g.py, g.pz));
                             f = ld3(sh.col); type = sh.type; lig = ld3(sh.lig);
                             if (primary && sub == 0 && smp == 0 && prim) prim[outk] = -1 - ids;
                         } else { // getn() returns the face normal (polygon.h:67-69)
-                            const TriShade *sh = S.tshade + tpos;
+                            const TriShade *sh = c_tshade + tpos;
                             x = o + d * to;
                             n = ld3(sh->nc);
                             f = ld3(sh->col); type = sh->type; lig = ld3(sh->lig);
@@ -1014,7 +1071,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                                     const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
                                     double u, v;
                                     tri_uv(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d, u, v);
-                                    f = tex_color(S.tex, ((const TexTri *)(S.tex + TEX_OFF_TRI))[tt - 1], u, v);
+                                    const unsigned char *tb = as_global(C.tex);
+                                    f = tex_color(tb, ((const TexTri *)(tb + TEX_OFF_TRI))[tt - 1], u, v);
                                 }
                             }
                             if (primary && sub == 0 && smp == 0 && prim) prim[outk] = sh->gid;
@@ -1125,24 +1183,24 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     const unsigned long long want = __ballot(need_work);
                     if (want == 0) break;
                     const unsigned k = (unsigned)__popcll(want);
-                    const unsigned was_base = sStash[0], was_n = sStash[1];
+                    const unsigned was_base = stash_get(0), was_n = stash_get(1);
                     const unsigned take = k <= was_n ? 0u : TRACE ? k : ((k - was_n + 15u) & ~15u); // (sixteen at a time: fewer trips to the counter)
                     unsigned base = 0;
                     const int leader = __ffsll((long long)want) - 1;
                     if (take != 0 && lane == leader) base = atomicAdd(counter, take);
                     base = __shfl(base, leader, 64);
                     if (lane == leader) {
-                        if (k >= was_n) { sStash[0] = base + (k - was_n); sStash[1] = take - (k - was_n); }
-                        else { sStash[0] = was_base + k; sStash[1] = was_n - k; }
+                        if (k >= was_n) { stash_put(0, base + (k - was_n)); stash_put(1, take - (k - was_n)); }
+                        else { stash_put(0, was_base + k); stash_put(1, was_n - k); }
                     }
                     if (need_work) {
                         const unsigned r = (unsigned)__popcll(want & lane_lt);
                         const unsigned w = r < was_n ? was_base + r : base + (r - was_n);
                         if (w >= n_work) { need_work = false; done = true; }
-                        else if (TRACE) { outk = w; need_work = false; go_on = true; ro = ld3(rays + 6 * (size_t)w); rd = ld3(rays + 6 * (size_t)w + 3); }
+                        else if (TRACE) { outk = w; need_work = false; go_on = true; const double *rp = as_global(C.rays) + 6 * (size_t)w; ro = ld3(rp); rd = ld3(rp + 3); }
                         else {
                             const unsigned blk = w >> 8, li = (w >> 2) & 63; // a block of 8 x 8 pixels is 256 pieces: pixel, sub-pixel
-                            const DevTile T = tiles[blk_tile[blk]]; // the tile this block belongs to
+                            const DevTile T = as_global(C.tiles)[as_global(C.blk_tile)[blk]]; // the tile this block belongs to
                             const int bq = (int)blk - T.blk_first;
                             const int lrow = (bq / T.blk_cols) * 8 + (int)(li >> 3), lcol = (bq % T.blk_cols) * 8 + (int)(li & 7);
                             if (lrow < T.rows && lcol < T.cols) { // ragged edge blocks have unused lanes
@@ -1186,7 +1244,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                 if (go_on) { // KdTree::check on the root (raytrace.cpp:46)
                     const double ix = fabs(rd.x) < 1e-150 ? 1e300 : 1.0 / rd.x, iy = fabs(rd.y) < 1e-150 ? 1e300 : 1.0 / rd.y,
                                  iz = fabs(rd.z) < 1e-150 ? 1e300 : 1.0 / rd.z;
-                    const float gf = ray_margin_factor(S.cen, S.reach, S.absn, ro.x, ro.y, ro.z, sqrt(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z));
+                    const float gf = ray_margin_factor(C.cen, C.reach, C.absn, ro.x, ro.y, ro.z, sqrt(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z));
                     sA[slot] = make_double2(ro.x, ro.y);
                     sB[slot] = make_double2(ro.z, ix);
                     sC[slot] = make_double2(iy, iz);
@@ -1196,7 +1254,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
                     ls[LS_HA * lss] = __longlong_as_double(-1ll);                   // no triangle
                     sG[slot] = exp_up_put(gf);
                     // beyond the factor (4 * reach + 1 at upload) that the lists' working coefficients cover: the larger ones
-                    st = gf <= (float)(3.9 * S.reach) ? 0u : ST_FAR;
+                    st = gf <= (float)(3.9 * C.reach) ? 0u : ST_FAR;
                     sp = 0; slo = 0;
                     if (SPH) { // many spheres: their hierarchy is searched after the kd-tree, from the bottom of the stack
                         const bool unit = fabs(dot(rd, rd) - 1.0) <= 1e-12; // what the boxes' inflation assumes
@@ -1273,6 +1331,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) void k_main(DevScene S, DevCame
 #undef RT_SCOUNT
 }
 
+// Writes a launch's cold arguments to their place in device memory (they arrive as a kernel argument, so nothing is
+// copied from host memory and the write is ordered with the launches on the stream).
+__global__ void k_put_cold(ColdArgs a, ColdArgs *dst) { *dst = a; }
+
 __global__ void k_fp64(int op, long long n, const double *a, const double *b, double *out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1285,7 +1347,7 @@ __global__ void k_fp64(int op, long long n, const double *a, const double *b, do
 // in device memory that exists from the moment the library is loaded.  Each GPU holds its own copy.
 constexpr size_t NA_MAX_PIXELS = RT_NOALLOC_MAX_PIXELS, NA_MAX_TILES = RT_NOALLOC_MAX_TILES, NA_MAX_BLOCKS = RT_NOALLOC_MAX_BLOCKS;
 constexpr size_t na_align(size_t x) { return (x + 255) & ~(size_t)255; }
-constexpr size_t NA_OFF_COUNTER = 0, NA_OFF_TILES = 256, NA_OFF_BLK = NA_OFF_TILES + na_align(NA_MAX_TILES * sizeof(DevTile)),
+constexpr size_t NA_OFF_COUNTER = 0, NA_OFF_COLD = 256, NA_OFF_TILES = NA_OFF_COLD + na_align(sizeof(ColdArgs)), NA_OFF_BLK = NA_OFF_TILES + na_align(NA_MAX_TILES * sizeof(DevTile)),
                  NA_OFF_CNT = NA_OFF_BLK + na_align(NA_MAX_BLOCKS * sizeof(int)),
                  NA_OFF_SUB = NA_OFF_CNT + na_align(NA_MAX_PIXELS * sizeof(unsigned)),
                  NA_BYTES = NA_OFF_SUB + na_align(NA_MAX_PIXELS * 12 * sizeof(double));
@@ -1348,6 +1410,8 @@ int fail(int code, const char *fmt, ...) {
 struct rt_scene {
     int dev = 0;
     DevScene d{};
+    ColdArgs cold{};            // the scene's part of the cold arguments (shading records, scene extent)
+    ColdArgs *d_cold = nullptr; // where a launch's cold arguments go
     void *pool = nullptr, *tshade = nullptr, *tlist = nullptr, *sph = nullptr, *sshade = nullptr, *tex = nullptr;
     void *ovf = nullptr, *lstate = nullptr, *lhdr = nullptr;
     int tree_depth = 0;
@@ -1373,8 +1437,7 @@ struct rt_scene {
     int slots = 0;               // its slots per workgroup
 };
 
-using KernelFn = void (*)(DevScene, DevCamera, rt_params, const DevTile *, int, unsigned, unsigned *, double *, int *, const double *, int *,
-                          double *, int *, double *, unsigned long long *, double *, unsigned *, const int *);
+using KernelFn = void (*)(DevScene, const ColdArgs *, unsigned long long *);
 template <bool TRACE, bool TEX>
 KernelFn pick_kernel2(bool sph, bool deep) {
     if (deep) return sph ? k_main<TRACE, true, TEX, CFG_DEEP.slots, CFG_DEEP.ring> : k_main<TRACE, false, TEX, CFG_DEEP.slots, CFG_DEEP.ring>;
@@ -1383,7 +1446,9 @@ KernelFn pick_kernel2(bool sph, bool deep) {
 // (explicit-ray queries never shade: they have no textured instance)
 template <bool TRACE>
 KernelFn pick_kernel(bool sph, bool deep, bool tex) {
+#ifndef RT_NO_TEX // (experiment builds without the textured instances)
     if (!TRACE && tex) return pick_kernel2<false, true>(sph, deep);
+#endif
     return pick_kernel2<TRACE, false>(sph, deep);
 }
 
@@ -1834,10 +1899,15 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     const DevCamera dc = make_camera(cam);
     const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + s->slots - 1) / s->slots);
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep, s->d.tex != nullptr);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, dc, *p, (const DevTile *)s->d_tiles, n_tiles,
-                       (unsigned)(blocks * 256), s->d_counter, d_rgb, d_prim, (const double *)nullptr, (int *)nullptr,
-                       (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats, s->d_sub, s->d_subcnt, (const int *)s->d_blk_tile);
+    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep, s->cold.tex != nullptr);
+    ColdArgs ca = s->cold;
+    ca.cam = dc; ca.P = *p;
+    ca.tiles = s->d_tiles; ca.blk_tile = s->d_blk_tile; ca.counter = s->d_counter;
+    ca.rgb = d_rgb; ca.prim = d_prim; ca.subbuf = s->d_sub; ca.subcnt = s->d_subcnt;
+    ca.n_work = (unsigned)(blocks * 256); ca.n_tiles = n_tiles;
+    hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, stream, ca, s->d_cold);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, (const ColdArgs *)s->d_cold, s->d_stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     s->timed = true;
@@ -2118,6 +2188,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_slots * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&s->lstate, (size_t)LS_WORDS * n_slots * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_counter, 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_cold, sizeof(ColdArgs));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&s->ev0);
@@ -2128,19 +2199,19 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         return fail(RT_E_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
     }
     s->d.pool = (const char *)s->pool;
-    s->d.tshade = (const TriShade *)s->tshade;
+    s->cold.tshade = (const TriShade *)s->tshade;
     s->d.tlist = (const uint2 *)s->tlist;
-    s->d.sph = (const SphGeom *)s->sph;
-    s->d.sshade = (const SphShade *)s->sshade;
-    s->d.tex = n_textri ? (const unsigned char *)s->tex : nullptr;
+    s->cold.sph = (const SphGeom *)s->sph;
+    s->cold.sshade = (const SphShade *)s->sshade;
+    s->cold.tex = n_textri ? (const unsigned char *)s->tex : nullptr;
     s->d.ovf = (unsigned *)s->ovf;
     s->d.lstate = (double *)s->lstate;
-    s->d.reach = std::sqrt(lg2) * 1.000001;
-    s->d.absn = 0;
+    s->cold.reach = std::sqrt(lg2) * 1.000001;
+    s->cold.absn = 0;
     for (int k = 0; k < 3; k++) {
-        s->d.cen[k] = 0.5 * (blo[k] + bhi[k]);
-        s->d.reach += 0.5 * (bhi[k] - blo[k]) * 1.000001;
-        s->d.absn += std::fabs(s->d.cen[k]) + 0.5 * (bhi[k] - blo[k]);
+        s->cold.cen[k] = 0.5 * (blo[k] + bhi[k]);
+        s->cold.reach += 0.5 * (bhi[k] - blo[k]) * 1.000001;
+        s->cold.absn += std::fabs(s->cold.cen[k]) + 0.5 * (bhi[k] - blo[k]);
     }
     double boxsum = 0;
     for (int i = 0; i < D->n_nodes; i++) {
@@ -2157,7 +2228,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     for (int k = 0; k < 3; k++) s->d.sph_cen[k] = sph_cen[k];
     s->d.sph_h = sph_h;
     s->d.lhdr = (const ListHdr *)s->lhdr;
-    s->d.fslack = f_up(16.0 * 5.97e-8 * (s->d.absn + s->d.reach)); // see the cull step
+    s->d.fslack = f_up(16.0 * 5.97e-8 * (s->cold.absn + s->cold.reach)); // see the cull step
     s->d.n_sph = D->n_spheres;
     s->d.ovf_depth = ovf_depth;
     s->d.n_slots = n_slots;
@@ -2168,7 +2239,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile};
+    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_cold, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -2224,11 +2295,15 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
     const DevCamera dc = make_camera(cam);
     const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + s->slots - 1) / s->slots);
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep, s->d.tex != nullptr);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, dc, *p, (const DevTile *)(scr + NA_OFF_TILES), n_tiles,
-                       (unsigned)(blocks * 256), (unsigned *)(scr + NA_OFF_COUNTER), d_rgb, d_prim_id, (const double *)nullptr, (int *)nullptr,
-                       (double *)nullptr, (int *)nullptr, (double *)nullptr, s->d_stats, (double *)(scr + NA_OFF_SUB),
-                       (unsigned *)(scr + NA_OFF_CNT), (const int *)(scr + NA_OFF_BLK));
+    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep, s->cold.tex != nullptr);
+    ColdArgs ca = s->cold;
+    ca.cam = dc; ca.P = *p;
+    ca.tiles = (const DevTile *)(scr + NA_OFF_TILES); ca.blk_tile = (const int *)(scr + NA_OFF_BLK); ca.counter = (unsigned *)(scr + NA_OFF_COUNTER);
+    ca.rgb = d_rgb; ca.prim = d_prim_id; ca.subbuf = (double *)(scr + NA_OFF_SUB); ca.subcnt = (unsigned *)(scr + NA_OFF_CNT);
+    ca.n_work = (unsigned)(blocks * 256); ca.n_tiles = n_tiles;
+    hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, stream, ca, (ColdArgs *)(scr + NA_OFF_COLD));
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, (const ColdArgs *)(scr + NA_OFF_COLD), s->d_stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     s->timed = true;
@@ -2324,12 +2399,13 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) {
         const long long want = (n + s->slots - 1) / s->slots;
         const int grid = (int)std::min<long long>(s->grid_trace, want); // stay within the slot count the state arrays were sized for
-        rt_params none = {1, 0, 0, 0, 1, 0, 0};
-        DevCamera nocam = {};
         const KernelFn kern = pick_kernel<true>(s->d.sph_root != 0, s->deep, false);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, nullptr, s->d, nocam, none, (const DevTile *)nullptr, 0,
-                           (unsigned)n, s->d_counter, (double *)nullptr, (int *)nullptr, (const double *)d_rays, d_ti, d_tt, d_si,
-                           d_st, s->d_stats, (double *)nullptr, (unsigned *)nullptr, (const int *)nullptr);
+        ColdArgs ca = s->cold;
+        ca.P = rt_params{1, 0, 0, 0, 1, 0, 0};
+        ca.counter = s->d_counter; ca.n_work = (unsigned)n;
+        ca.rays = d_rays; ca.tri_id = d_ti; ca.tri_t = d_tt; ca.sph_id = d_si; ca.sph_t = d_st;
+        hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, nullptr, ca, s->d_cold);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, nullptr, s->d, (const ColdArgs *)s->d_cold, s->d_stats);
         e = hipGetLastError();
         s->last_stream = nullptr;
     }
