@@ -50,8 +50,9 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/kdtree.cpp"):
         ref = os.path.join(_HERE, "_ref", "libref_l3.so")
-        h = os.path.join(_HERE, "ref_l3_harness.cpp")
-        if force or not os.path.exists(ref) or os.path.getmtime(ref) < os.path.getmtime(h):
+        deps = [os.path.join(_HERE, "ref_l3_harness.cpp"), os.path.join(_HERE, "..", "integration", "rt_binding.h"),
+                os.path.join(_HERE, "..", "include", "rt_hip.h")]
+        if force or not os.path.exists(ref) or os.path.getmtime(ref) < max(os.path.getmtime(d) for d in deps):
             subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -295,6 +296,8 @@ def ref_lib():
         R.ref_add_texture.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int]
         R.ref_add_object_tex.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, _dp]
         R.ref_poly_getcol.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
+        R.ref_flatten_desc.argtypes = [C.c_void_p]
+        R.ref_flatten_desc.restype = C.c_void_p
         R.ref_build.argtypes = [C.c_void_p]
         R.ref_check.argtypes = [C.c_void_p, _dp, _ip, _ip, _dp]
         R.ref_sphere_intersect.argtypes = [C.c_void_p, _dp, _ip, _dp]
@@ -343,6 +346,10 @@ class RefScene:
                                              None if tc is None else _d(tc), None if vn is None else _d(vn), int(type_), _i(tt), _d(ts))
         return self.R.ref_add_object(self.h, _d(v), v.shape[0], _d(_c3(lig)), _d(_c3(col)),
                                      None if tc is None else _d(tc), None if vn is None else _d(vn), int(type_))
+
+    def flatten_desc(self):
+        """Address of the rt_scene_desc that integration/rt_binding.h builds from the reference's objects."""
+        return self.R.ref_flatten_desc(self.h)
 
     def poly_getcol(self, gid, u, v):
         no, nv = self.split_gid(gid)

@@ -22,6 +22,7 @@
 #include "object.h"
 #include "sphere.h"
 #include "kdtree.h"
+#include "rt_binding.h" // integration/rt_binding.h: the reference-side flattening, compiled here against the reference's own headers
 
 struct RefTex { std::vector<unsigned char> data; int sizex, sizey; };
 struct RefScene {
@@ -197,6 +198,14 @@ void ref_primary_ray(const double *camo, const double *dvec, double *out) {
     Ray cam(o, Point3D(0, 0, -1));
     Ray r = Ray(cam.o + d * 140, d.norm());
     out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z;
+}
+
+// The description integration/rt_binding.h makes of this scene's reference objects.  The RtFlat stays alive with the
+// scene (leaked with it, like the reference's tree); returns a pointer to its rt_scene_desc.
+const void *ref_flatten_desc(void *h) {
+    RefScene *s = (RefScene *)h;
+    RtFlat *f = new RtFlat();
+    return rt_flatten(s->objs, s->spheres, s->tree, *f);
 }
 
 // Vector helpers of point.h for known-answer tests.

@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -47,6 +48,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_hip.h"
@@ -648,12 +650,6 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
         unsigned push_item = 0; // item to push before that (0 = none; the root is never pushed)
         bool done = false;      // the slot found no more work
         RT_TICK(tk1);
-#ifdef RT_WAIT_TOP
-        // Nothing of the previous step is still in flight when a step issues its loads: otherwise the compiler, which
-        // cannot know which kind of step ran last, guards the first reuse of any register a conditional load of ANY
-        // step may still be writing with a full wait -- in the middle of this step's own loads.
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-#endif
 
         if (pick == K_NODE) {
             const bool refill = run && cur == IT_REFILL;
@@ -1427,6 +1423,9 @@ struct rt_scene {
     double *d_sub = nullptr;     // shares of the sub-pixels of the frame being rendered [pixel][4][3]
     unsigned *d_subcnt = nullptr; // finished sub-pixels per pixel
     size_t sub_cap = 0;          // pixels both hold
+    double *d_stage_rgb = nullptr; // rt_render_tile's device-side output buffers, kept between calls
+    int *d_stage_prim = nullptr;
+    size_t stage_cap = 0;        // pixels both hold
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_tables = nullptr;       // recorded behind the last upload of the tile tables
     hipStream_t tables_stream = nullptr;  // the stream that upload was queued on
@@ -1980,42 +1979,96 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     }
     std::vector<int> order((size_t)D->n_list); // device position -> entry of list_tri
     for (int i = 0; i < D->n_list; i++) order[i] = i;
+    // The nodes' records and their lists' hierarchies, built in parallel: chunks of nodes are handed to worker threads,
+    // each chunk collects its culling records in a vector of its own (numbered from zero), and afterwards the chunks
+    // are laid end to end in node order and the record numbers shifted accordingly -- the same layout a single
+    // thread walking the nodes in order produces.
     int cull_depth = 0;
-    for (int i = 0; i < D->n_nodes; i++) {
-        NodeRec n;
-        for (int k = 0; k < 3; k++) { n.mi[k] = D->node_box[6 * i + k]; n.ma[k] = D->node_box[6 * i + 3 + k]; }
-        n.split = D->node_split[i];
-        n.right = D->node_right[i] > 0 ? 4u * (unsigned)D->node_right[i] : 0u;
-        n.info = (unsigned)D->node_axis[i] | (D->node_left[i] >= 0 ? 4u : 0u) | ((unsigned)D->node_count[i] << 3);
-        QuadRec li;
-        memset(&li, 0, sizeof(li));
-        ListHdr &hdr = lhdr[i];
-        const int cnt = D->node_count[i], first = D->node_first[i];
-        double klo[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, khi[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        bool has[3] = {false, false, false};
-        if (cnt > SMALL_LIST) {
-            build_list(D, first, cnt, order, cull, (unsigned)g_cull, (unsigned)g_tri, li, hdr, cull_depth, g0, klo[2], khi[2]);
-            has[2] = true;
-        } else {
-            hdr.meta = LIST_SHORT | (unsigned)cnt;
-            li.item[0] = IT_TRI | IT_CHAIN | ((unsigned)g_tri + 5u * (unsigned)first);
-        }
-        hdr.right = n.right;
-        {
-            KidRec kr;
-            const int kid[2] = {D->node_left[i] >= 0 ? i + 1 : -1, D->node_right[i] > 0 ? D->node_right[i] : -1};
-            for (int c = 0; c < 2; c++) {
-                has[c] = kid[c] >= 0;
-                if (has[c])
-                    for (int k = 0; k < 3; k++) { klo[c][k] = D->node_box[6 * (size_t)kid[c] + k]; khi[c][k] = D->node_box[6 * (size_t)kid[c] + 3 + k]; }
+    {
+        constexpr int CHUNK = 2048;
+        const int n_chunks = (D->n_nodes + CHUNK - 1) / CHUNK;
+        std::vector<std::vector<QuadRec>> chunk_cull((size_t)n_chunks);
+        std::vector<int> chunk_depth((size_t)n_chunks, 0);
+        std::atomic<int> next_chunk(0);
+        auto work = [&]() {
+            for (;;) {
+                const int c = next_chunk.fetch_add(1);
+                if (c >= n_chunks) break;
+                std::vector<QuadRec> &lc = chunk_cull[(size_t)c];
+                for (int i = c * CHUNK; i < std::min(D->n_nodes, (c + 1) * CHUNK); i++) {
+                    NodeRec n;
+                    for (int k = 0; k < 3; k++) { n.mi[k] = D->node_box[6 * (size_t)i + k]; n.ma[k] = D->node_box[6 * (size_t)i + 3 + k]; }
+                    n.split = D->node_split[i];
+                    n.right = D->node_right[i] > 0 ? 4u * (unsigned)D->node_right[i] : 0u;
+                    n.info = (unsigned)D->node_axis[i] | (D->node_left[i] >= 0 ? 4u : 0u) | ((unsigned)D->node_count[i] << 3);
+                    QuadRec li;
+                    memset(&li, 0, sizeof(li));
+                    ListHdr &hdr = lhdr[i];
+                    const int cnt = D->node_count[i], first = D->node_first[i];
+                    double klo[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, khi[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                    bool has[3] = {false, false, false};
+                    if (cnt > SMALL_LIST) { // (disjoint ranges of `order` per list)
+                        build_list(D, first, cnt, order, lc, (unsigned)g_cull, (unsigned)g_tri, li, hdr, chunk_depth[(size_t)c], g0, klo[2], khi[2]);
+                        has[2] = true;
+                    } else {
+                        hdr.meta = LIST_SHORT | (unsigned)cnt;
+                        li.item[0] = IT_TRI | IT_CHAIN | ((unsigned)g_tri + 5u * (unsigned)first);
+                    }
+                    hdr.right = n.right;
+                    {
+                        KidRec kr;
+                        const int kid[2] = {D->node_left[i] >= 0 ? i + 1 : -1, D->node_right[i] > 0 ? D->node_right[i] : -1};
+                        for (int c2 = 0; c2 < 2; c2++) {
+                            has[c2] = kid[c2] >= 0;
+                            if (has[c2])
+                                for (int k = 0; k < 3; k++) { klo[c2][k] = D->node_box[6 * (size_t)kid[c2] + k]; khi[c2][k] = D->node_box[6 * (size_t)kid[c2] + 3 + k]; }
+                        }
+                        kid_fill(kr, klo, khi, has);
+                        if (cnt == 0) kr.flags |= KID_EMPTY;
+                        kr.meta = hdr.meta;
+                        memcpy(&pool[(g_kid + 3 * (size_t)i) * 16], &kr, 48);
+                    }
+                    memcpy(&pool[(size_t)i * 64], &n, 64);
+                    memcpy(&pool[(g_list + 4 * (size_t)i) * 16], &li, 64);
+                }
             }
-            kid_fill(kr, klo, khi, has);
-            if (cnt == 0) kr.flags |= KID_EMPTY;
-            kr.meta = hdr.meta;
-            memcpy(&pool[(g_kid + 3 * (size_t)i) * 16], &kr, 48);
+        };
+        int n_threads = 16; // (a one-GPU job's share of the host; the machine may show many more CPUs)
+        if (const char *e = getenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_threads = v; }
+        n_threads = std::max(1, std::min(n_threads, std::min(n_chunks, (int)std::max(1u, std::thread::hardware_concurrency()))));
+        if (n_threads == 1) work();
+        else {
+            std::vector<std::thread> pool_threads;
+            for (int t = 0; t < n_threads; t++) pool_threads.emplace_back(work);
+            for (auto &t : pool_threads) t.join();
         }
-        memcpy(&pool[(size_t)i * 64], &n, 64);
-        memcpy(&pool[(g_list + 4 * (size_t)i) * 16], &li, 64);
+        // chunks end to end; a culling item names its record by granule, so every such item of a chunk moves by the
+        // chunk's start (in the chunk's own records and in its nodes' list records)
+        size_t total = 0;
+        for (const auto &lc : chunk_cull) total += lc.size();
+        cull.reserve(total + 1);
+        auto shift_items = [](QuadRec &q, unsigned by) {
+            for (int k = 0; k < 4; k++)
+                if (q.item[k] != 0 && ((q.item[k] >> 29) & 3u) == 1u) q.item[k] += by;
+        };
+        for (int c = 0; c < n_chunks; c++) {
+            const unsigned by = 4u * (unsigned)cull.size();
+            std::vector<QuadRec> &lc = chunk_cull[(size_t)c];
+            cull_depth = std::max(cull_depth, chunk_depth[(size_t)c]);
+            if (lc.empty()) continue;
+            if (by) {
+                for (QuadRec &q : lc) shift_items(q, by);
+                for (int i = c * CHUNK; i < std::min(D->n_nodes, (c + 1) * CHUNK); i++)
+                    if (D->node_count[i] > SMALL_LIST) {
+                        QuadRec li;
+                        memcpy(&li, &pool[(g_list + 4 * (size_t)i) * 16], 64);
+                        shift_items(li, by);
+                        memcpy(&pool[(g_list + 4 * (size_t)i) * 16], &li, 64);
+                    }
+            }
+            cull.insert(cull.end(), lc.begin(), lc.end());
+            std::vector<QuadRec>().swap(lc);
+        }
     }
     // Scenes with many spheres: the same kind of hierarchy over the spheres' boxes, searched after the kd-tree
     // (the reference scans all of them for every ray, sphere.cpp:3-14).  Its root is one more cull record.
@@ -2239,7 +2292,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_cold, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile};
+    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_cold, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile, s->d_stage_rgb, s->d_stage_prim};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -2355,11 +2408,17 @@ int rt_render_tile(rt_scene *s, const rt_camera *cam, const rt_tile *tile, const
     if (tile->rows < 1 || tile->cols < 1) return fail(RT_E_INVALID, "empty tile");
     HIP_TRY(hipSetDevice(s->dev));
     const size_t npix = (size_t)tile->rows * tile->cols;
-    double *d_rgb = nullptr;
-    int *d_prim = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_rgb, npix * 3 * sizeof(double)));
-    hipError_t e = hipMalloc((void **)&d_prim, npix * sizeof(int));
-    if (e != hipSuccess) { (void)hipFree(d_rgb); return fail(RT_E_DEVICE, "hipMalloc: %s", hipGetErrorString(e)); }
+    if (npix > s->stage_cap) { // the staging buffers grow to the largest tile seen and stay until rt_free_scene
+        if (s->d_stage_rgb) (void)hipFree(s->d_stage_rgb);
+        if (s->d_stage_prim) (void)hipFree(s->d_stage_prim);
+        s->d_stage_rgb = nullptr; s->d_stage_prim = nullptr; s->stage_cap = 0;
+        HIP_TRY(hipMalloc((void **)&s->d_stage_rgb, npix * 3 * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&s->d_stage_prim, npix * sizeof(int)));
+        s->stage_cap = npix;
+    }
+    double *const d_rgb = s->d_stage_rgb;
+    int *const d_prim = s->d_stage_prim;
+    hipError_t e = hipSuccess;
     int rc = RT_OK;
     if (hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long)) != hipSuccess) rc = fail(RT_E_DEVICE, "hipMemset failed");
     if (!rc) rc = launch_render(s, cam, tile, 1, p, d_rgb, d_prim, nullptr);
@@ -2369,8 +2428,6 @@ int rt_render_tile(rt_scene *s, const rt_camera *cam, const rt_tile *tile, const
         if (e == hipSuccess && prim_id_out) e = hipMemcpy(prim_id_out, d_prim, npix * sizeof(int), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(RT_E_DEVICE, "render failed: %s", hipGetErrorString(e));
     }
-    (void)hipFree(d_rgb);
-    (void)hipFree(d_prim);
     rt_stats own; // the counters are fetched (and thereby cleared) whether or not the caller wants them
     if (!rc) rc = rt_get_stats(s, stats ? stats : &own);
     return rc;

@@ -83,3 +83,59 @@ def test_textured_getcol_matches_reference(ref):
                 assert np.array_equal(a, b), (g, u, v)
                 seen.add(tuple(a))
         assert len(seen) > 100  # many different texels were read
+
+
+def _desc_arrays(d):
+    """Every array of an rt_scene_desc (ctypes struct) as numpy copies."""
+    import ctypes as C
+    nn, nt, ns, nx = d.n_nodes, d.n_tris, d.n_spheres, d.n_textures
+
+    def arr(ptr, n, dt):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt).copy() if n else np.zeros(0, dt)
+    out = dict(n=(nn, d.n_list, d.tree_depth, nt, ns, nx),
+               box=arr(d.node_box, 6 * nn, np.float64), split=arr(d.node_split, nn, np.float64), axis=arr(d.node_axis, nn, np.int32),
+               left=arr(d.node_left, nn, np.int32), right=arr(d.node_right, nn, np.int32), first=arr(d.node_first, nn, np.int32),
+               count=arr(d.node_count, nn, np.int32), list=arr(d.list_tri, d.n_list, np.int32),
+               verts=arr(d.tri_verts, 9 * nt, np.float64), nc=arr(d.tri_nc, 3 * nt, np.float64), col=arr(d.tri_col, 3 * nt, np.float64),
+               lig=arr(d.tri_lig, 3 * nt, np.float64), type=arr(d.tri_type, nt, np.int32),
+               srad=arr(d.sph_rad, ns, np.float64), spos=arr(d.sph_pos, 3 * ns, np.float64), slig=arr(d.sph_lig, 3 * ns, np.float64),
+               scol=arr(d.sph_col, 3 * ns, np.float64), stype=arr(d.sph_type, ns, np.int32))
+    if nx:
+        out["tri_tex"] = arr(d.tri_tex, nt, np.int32)
+        ts = arr(d.tri_ts, 6 * nt, np.float64).reshape(nt, 6)
+        out["tri_ts"] = ts[out["tri_tex"] >= 0]
+        out["images"] = [arr(d.tex_data, d.tex_offset[k] + 3 * d.tex_sizex[k] * d.tex_sizey[k], np.uint8)[d.tex_offset[k]:].reshape(d.tex_sizey[k], d.tex_sizex[k], 3)
+                         for k in range(nx)]
+    return out
+
+
+def test_reference_side_binding_produces_the_host_librarys_description(ref, ra):
+    """integration/rt_binding.h -- the flattening a maintainer adds to raytrace.cpp -- compiled against the reference's
+    real headers and run on the reference's own Object / Polygon / Sphere / KdTree instances: the rt_scene_desc it
+    produces equals the one librt_host.so builds for the same scene, array by array and bit for bit (images
+    compared by content: the two number them in different orders)."""
+    import ctypes as C
+    from raytrace_amd import scenes
+    for sc in (scenes.tiny_mixed(3, n_tris=300, n_sph=7), scenes.cornell_demo(), scenes.sponza_class(20000, detail=0.2),
+               scenes.deep_tree(), scenes.textured_room()):
+        rf = ref.RefScene(sc)
+        a = _desc_arrays(C.cast(rf.flatten_desc(), C.POINTER(ra.capi.SceneDesc)).contents)
+        hs = ra.HostScene(sc)
+        b = _desc_arrays(hs.desc.contents)
+        assert a["n"][:5] == b["n"][:5], (a["n"], b["n"])
+        for k in b:
+            if k in ("n", "tri_tex", "images"):
+                continue
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+        if "images" in b:
+            assert np.array_equal(a["tri_tex"] >= 0, b["tri_tex"] >= 0)
+            for ia, ib in zip(a["tri_tex"], b["tri_tex"]):
+                if ib >= 0:
+                    assert np.array_equal(a["images"][ia], b["images"][ib])
+        # and the device library accepts it as far as a machine without a GPU lets it go: validation passes
+        h = C.c_void_p()
+        rc = ra.capi.device_lib().rt_upload_scene(0, C.cast(rf.flatten_desc(), C.POINTER(ra.capi.SceneDesc)), C.byref(h))
+        if rc == 0:
+            ra.capi.device_lib().rt_free_scene(h)
+        else:
+            assert rc == -2, ra.capi.device_lib().rt_last_error()  # RT_E_DEVICE: no GPU here; never RT_E_INVALID
