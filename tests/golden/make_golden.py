@@ -180,5 +180,6 @@ if __name__ == "__main__":
     make("bunny2k", scenes.bunny_class(2000), np.array([50, 30, 80.0]), 50.0, 1500)
     make("sponza12k", scenes.sponza_class(12000, detail=0.12), np.array([50, 40, 130.0]), 60.0, 1000)
     make("texroom", scenes.textured_room(), np.array([20, 30, 20.0]), 50.0, 1000)
+    make("deeptree", scenes.deep_tree(), np.array([250, 250, 250.0]), 450.0, 1500)  # a 42-level tree
     make_aabb()
     make_primary()

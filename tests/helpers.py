@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SCENE_FIXTURES = ["tiny0", "tiny5", "cornell", "bunny2k", "sponza12k", "texroom"]
+SCENE_FIXTURES = ["tiny0", "tiny5", "cornell", "bunny2k", "sponza12k", "texroom", "deeptree"]
 
 
 def load_fixture(name):

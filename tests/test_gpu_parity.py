@@ -65,7 +65,7 @@ def test_trace_rays_bit_exact(world, name):
     assert (tid >= 0).sum() > 0 or name == "cornell"
 
 
-@pytest.mark.parametrize("name", ["tiny0", "tiny5", "cornell", "bunny2k", "sponza12k"])
+@pytest.mark.parametrize("name", ["tiny0", "tiny5", "cornell", "bunny2k", "sponza12k", "texroom", "deeptree"])
 def test_trace_rays_match_reference_golden_vectors(ra, name):
     """The HIP path against vectors recorded from the reference's own object code (tests/golden)."""
     from helpers import load_fixture, scene_from_fixture
