@@ -102,7 +102,7 @@ typedef struct rt_tile {
 } rt_tile;
 
 /*
- * Integrator controls.  reference behaviour = {samps, 5, 1, 2, <large>, 1, seed}.
+ * Integrator controls.  reference behaviour = {samps, 5, 1, 2, <large>, 1, seed, 0, 0}.
  *   rr_depth    Russian roulette starts once ++depth > rr_depth       (raytrace.cpp:70; reference 5)
  *   rr_mode     1: roulette with survival probability max(f)          (raytrace.cpp:71-74)
  *               0: the path ends there and returns the emission -- a hard depth bound
@@ -112,6 +112,13 @@ typedef struct rt_tile {
  *               0: dx = dy = 0 and no draws are consumed
  *   seed        every path (pixel, sub-pixel, sample) restarts the drand48 recurrence from a state
  *               hashed from (seed, path index), so results do not depend on tiling or GPU count
+ *   light_mode  0: the reference's integrator -- emission is found by the paths alone
+ *               1: explicit light sampling ("shadow rays"); NO counterpart in the reference (its light.h is
+ *                  never used).  At every diffuse hit one emissive sphere, picked uniformly, is sampled over
+ *                  the cone it subtends (three more draws, after the bounce's two) and a shadow ray -- a ray
+ *                  like any other in the counters -- decides whether it is seen; the bounce ray then adds no
+ *                  emissive sphere's emission at its hit.  Emissive triangles are never sampled and always
+ *                  add.  Converges to the same image as mode 0, with less noise for small lights.
  */
 typedef struct rt_params {
     int32_t samps;
@@ -121,6 +128,8 @@ typedef struct rt_params {
     int32_t hard_depth;
     int32_t jitter;
     uint64_t seed;
+    int32_t light_mode;
+    int32_t reserved; /* 0 */
 } rt_params;
 
 /* Work counters. A ray is one nearest-hit query = one radiance() invocation of the reference. */

@@ -35,7 +35,7 @@ class OStats(C.Structure):
 
 class OParams(C.Structure):
     _fields_ = [("samps", C.c_int32), ("rr_depth", C.c_int32), ("rr_mode", C.c_int32), ("split_depth", C.c_int32),
-                ("hard_depth", C.c_int32), ("jitter", C.c_int32), ("seed", C.c_uint64)]
+                ("hard_depth", C.c_int32), ("jitter", C.c_int32), ("seed", C.c_uint64), ("light_mode", C.c_int32)]
 
 
 class OCamera(C.Structure):
@@ -115,8 +115,8 @@ def _bind(L):
     return L
 
 
-def make_params(samps=1, rr_depth=5, rr_mode=1, split_depth=2, hard_depth=64, jitter=1, seed=1):
-    return OParams(samps, rr_depth, rr_mode, split_depth, hard_depth, jitter, seed)
+def make_params(samps=1, rr_depth=5, rr_mode=1, split_depth=2, hard_depth=64, jitter=1, seed=1, light_mode=0):
+    return OParams(samps, rr_depth, rr_mode, split_depth, hard_depth, jitter, seed, light_mode)
 
 
 def make_camera(o, d, sizex, sizey):

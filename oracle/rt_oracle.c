@@ -29,7 +29,7 @@
  * reference's own object code (oracle/_ref, built from the reference's
  * kdtree.cpp / sphere.cpp / headers) by tests/test_oracle_vs_ref.py and by the
  * golden vectors under tests/golden/.  `radiance`, the pixel loop and drawPixel
- * live in raytrace.cpp, which needs mpi.h and OpenCV headers that this image does
+ * live in raytrace.cpp, which needs OpenCV headers that this image does
  * not have, so that file cannot be compiled here: for those functions this file
  * is a careful restatement and their parity is UNPINNED.
  *
@@ -47,6 +47,12 @@
  *   split_depth       (reference: both glass branches while depth <= 2)
  *   hard_depth        (reference: unbounded recursion)      -> safety cap
  *   jitter            (reference: always on)                -> id maps
+ *   light_mode        (reference: none, light.h is unused)  -> 1 = explicit light sampling:
+ *                     at every diffuse hit one emissive sphere, picked uniformly, is sampled
+ *                     over the cone it subtends and a shadow ray decides whether it is seen;
+ *                     the next hit then does not add an emissive sphere's emission again.
+ *                     No counterpart in the reference, so this mode's parity is UNPINNED by
+ *                     construction; it converges to the same image as mode 0.
  */
 #include <math.h>
 #include <stdint.h>
@@ -502,18 +508,71 @@ typedef struct {
     int32_t hard_depth;  /* stop (return emission) once ++depth > hard_depth; reference recursion is unbounded */
     int32_t jitter;      /* 1 = tent-filter draws (reference); 0 = dx=dy=0 and no draws consumed */
     uint64_t seed;
+    int32_t light_mode;  /* 0 = reference (emission found by the paths alone); 1 = explicit light sampling */
 } oparams;
 
 typedef struct {
     const oscene *sc; const oparams *pr; rng48 rng; ostats st;
     int first_id; /* id of the first ray's hit (triangle gid >=0, sphere -1-i, miss INT32_MIN) */
     int nrays_path;
+    const int *lights; int n_lights; /* emissive spheres, ascending index (light_mode 1) */
 } octx;
+
+/* Indices of the spheres with a non-zero emission, ascending; the caller frees. */
+static int *light_list(const oscene *sc, int *n) {
+    int *l = (int *)malloc(sizeof(int) * (sc->nsphs ? sc->nsphs : 1));
+    *n = 0;
+    for (int i = 0; i < sc->nsphs; i++)
+        if (sc->sphs[i].lig.x != 0 || sc->sphs[i].lig.y != 0 || sc->sphs[i].lig.z != 0) l[(*n)++] = i;
+    return l;
+}
 
 #define MISS_ID (-2147483647 - 1)
 
-/* raytrace.cpp:41-95 */
-static v3 radiance(octx *c, ray_t r, int depth, int into) {
+/* Explicit light sampling at a diffuse hit (light_mode 1; no counterpart in the reference).  xo is the
+ * origin the bounce ray starts from, nl the shading normal.  Three draws, always: which light, then the
+ * point in the cone.  Returns 1 if the light could be sampled (no emissive sphere's emission may then
+ * be added by the bounce ray), 0 if xo is inside it (the bounce ray then stands in for the sample: it adds
+ * that sphere's emission x number of lights, and no other sphere's); *which is the light; *e is its
+ * radiance x cosine x solid angle / pi x number of lights when the shadow ray's nearest hit is that
+ * light, else 0. */
+static int sample_light(octx *c, v3 xo, v3 nl, v3 *e, int *which) {
+    const oscene *sc = c->sc;
+    *e = V(0, 0, 0);
+    int k = (int)(rng_next(&c->rng) * c->n_lights);
+    if (k > c->n_lights - 1) k = c->n_lights - 1;
+    const double eps1 = rng_next(&c->rng), eps2 = rng_next(&c->rng);
+    const int target = c->lights[k];
+    const osph *s = &sc->sphs[target];
+    *which = target;
+    const v3 sv0 = vsub(s->pos, xo);
+    const double dist2 = vdot(sv0, sv0), rad2 = s->rad * s->rad;
+    if (!(dist2 > rad2)) return 0;
+    const v3 sw = vscale(sv0, 1 / sqrt(dist2));
+    const v3 su = vnorm(vcross(fabs(sw.x) > .1 ? V(0, 1, 0) : V(1, 0, 0), sw)), sv = vcross(sw, su);
+    const double cos_a_max = sqrt(1 - rad2 / dist2);
+    const double cos_a = 1 - eps1 + eps1 * cos_a_max, sin_a = sqrt(1 - cos_a * cos_a), phi = 2 * M_PI * eps2;
+    const v3 l = vnorm(vadd(vadd(vscale(vscale(su, cos(phi)), sin_a), vscale(vscale(sv, sin(phi)), sin_a)), vscale(sw, cos_a)));
+    const double cosl = vdot(l, nl);
+    if (!(cosl > 0)) return 1; /* below the horizon: no contribution, no shadow ray */
+    ray_t sr = {xo, l};
+    double ts, to = 1e20;
+    int ids = -1, idt = -1;
+    c->st.rays++;
+    c->nrays_path++;
+    const int fo = kd_check(sc, sc->root, &sr, &idt, &to, &c->st);
+    const int fs = sphere_intersect(sc, &sr, &ids, &ts, &c->st);
+    if (fs && (ts < to || !fo) && ids == target) {
+        const double omega = 2 * M_PI * (1 - cos_a_max);
+        *e = vscale(s->lig, cosl * omega * M_1_PI * c->n_lights);
+    }
+    return 1;
+}
+
+/* raytrace.cpp:41-95.  emit (light_mode 1 only; always 1 otherwise) says what an emissive SPHERE at the hit
+ * adds: 1 its emission; 0 nothing (the ray leaves a diffuse hit where a light was sampled explicitly);
+ * 2 its emission x number of lights if it is sphere `target`, else nothing (that light could not be sampled). */
+static v3 radiance(octx *c, ray_t r, int depth, int into, int emit, int target) {
     const oscene *sc = c->sc;
     double ts, to = 1e20;
     int ids = -1, idt = -1;
@@ -528,7 +587,7 @@ static v3 radiance(octx *c, ray_t r, int depth, int into) {
     if (ts < to || !fo) {
         const osph *obj = &sc->sphs[ids];
         x = vadd(r.o, vscale(r.d, ts)); n = vnorm(vsub(x, obj->pos)); nl = (vdot(n, r.d) < 0 ? n : vscale(n, -1));
-        f = obj->col; type = obj->type; lig = obj->lig;
+        f = obj->col; type = obj->type; lig = emit == 1 ? obj->lig : emit == 2 && ids == target ? vscale(obj->lig, c->n_lights) : V(0, 0, 0);
         if (primary) c->first_id = -1 - ids;
     } else {
         double u, v;
@@ -556,27 +615,33 @@ static v3 radiance(octx *c, ray_t r, int depth, int into) {
         v3 w = nl, u = vnorm(vcross(fabs(w.x) > .1 ? V(0, 1, 0) : V(1, 0, 0), w)), v = vcross(w, u);
         v3 d = vnorm(vadd(vadd(vscale(vscale(u, cos(r1)), r2s), vscale(vscale(v, sin(r1)), r2s)), vscale(w, sqrt(1 - r2))));
         ray_t nr = {vsub(x, vscale(r.d, EPS)), d};
-        return vadd(lig, vmult(f, radiance(c, nr, depth, into)));
+        if (c->pr->light_mode && c->n_lights > 0) {
+            v3 e;
+            int which;
+            const int sampled = sample_light(c, nr.o, nl, &e, &which);
+            return vadd(lig, vmult(f, vadd(e, radiance(c, nr, depth, into, sampled ? 0 : 2, which))));
+        }
+        return vadd(lig, vmult(f, radiance(c, nr, depth, into, 1, -1)));
     } else if (type == SPEC) {
         ray_t nr = {vsub(x, vscale(r.d, EPS)), vsub(r.d, vscale(vscale(n, 2), vdot(n, r.d)))};
-        return vadd(lig, vmult(f, radiance(c, nr, depth, into)));
+        return vadd(lig, vmult(f, radiance(c, nr, depth, into, 1, -1)));
     }
 
     ray_t reflRay = {vsub(x, vscale(r.d, EPS)), vsub(r.d, vscale(vscale(n, 2), vdot(n, r.d)))};
     double nc = 1, nt = 1.7, nnt = into ? nc / nt : nt / nc, ddn = vdot(r.d, nl), cos2t;
     if ((cos2t = 1 - nnt * nnt * (1 - ddn * ddn)) < 0) /* total internal reflection */
-        return vadd(lig, vmult(f, radiance(c, reflRay, depth, into)));
+        return vadd(lig, vmult(f, radiance(c, reflRay, depth, into, 1, -1)));
     v3 tdir = vnorm(vsub(vscale(r.d, nnt), vscale(n, ((into ? 1 : -1) * (ddn * nnt + sqrt(cos2t))))));
     double a = nt - nc, b = nt + nc, R0 = a * a / (b * b), cc = 1 - (into ? -ddn : vdot(tdir, n));
     double Re = R0 + (1 - R0) * cc * cc * cc * cc * cc, Tr = 1 - Re, P = .25 + .5 * Re, RP = Re / P, TP = Tr / (1 - P);
     ray_t refrRay = {vadd(x, vscale(r.d, EPS)), tdir};
     if (depth > c->pr->split_depth) {
-        if (rng_next(&c->rng) < P) return vadd(lig, vmult(f, vscale(radiance(c, reflRay, depth, into), RP)));
-        else return vadd(lig, vmult(f, vscale(radiance(c, refrRay, depth, !into), TP)));
+        if (rng_next(&c->rng) < P) return vadd(lig, vmult(f, vscale(radiance(c, reflRay, depth, into, 1, -1), RP)));
+        else return vadd(lig, vmult(f, vscale(radiance(c, refrRay, depth, !into, 1, -1), TP)));
     }
     /* both branches: refraction subtree consumes the stream first (g++ evaluation order) */
-    v3 Lt = radiance(c, refrRay, depth, !into);
-    v3 Lr = radiance(c, reflRay, depth, into);
+    v3 Lt = radiance(c, refrRay, depth, !into, 1, -1);
+    v3 Lr = radiance(c, reflRay, depth, into, 1, -1);
     return vadd(lig, vmult(f, vadd(vscale(Lr, Re), vscale(Lt, Tr))));
 }
 
@@ -603,14 +668,15 @@ void orc_primary_ray(const double *camo, const double *d, double *out) {
 }
 
 /* One pixel (row x, column y) of raytrace.cpp:196-205. */
-static void render_pixel(const oscene *sc, const ocamera *cam, const oparams *pr, int x, int y, double *rgb,
-                         int *prim_id, ostats *st) {
+static void render_pixel(const oscene *sc, const ocamera *cam, const oparams *pr, const int *lights, int n_lights, int x, int y,
+                         double *rgb, int *prim_id, ostats *st) {
     v3 camo = V(cam->o[0], cam->o[1], cam->o[2]);
     v3 camd = vnorm(V(cam->d[0], cam->d[1], cam->d[2]));
     v3 cy = V(cam->sizey * .5035 / cam->sizex, 0, 0), cx = vscale(vnorm(vcross(cy, camd)), -.5035);
     int sizex = cam->sizex, sizey = cam->sizey, samps = pr->samps;
     v3 col = V(0, 0, 0);
     octx c; c.sc = sc; c.pr = pr; memset(&c.st, 0, sizeof(c.st));
+    c.lights = lights; c.n_lights = n_lights;
     for (int sx = 0; sx < 2; sx++)
         for (int sy = 0; sy < 2; sy++) {
             v3 r = V(0, 0, 0);
@@ -630,7 +696,7 @@ static void render_pixel(const oscene *sc, const ocamera *cam, const oparams *pr
                 v3 dn = vnorm(d);
                 ray_t pr_ray = {vadd(camo, vscale(dn, 140)), dn};
                 c.nrays_path = 0; c.first_id = MISS_ID;
-                v3 L = radiance(&c, pr_ray, 0, 1);
+                v3 L = radiance(&c, pr_ray, 0, 1, 1, -1);
                 if (sx == 0 && sy == 0 && s == 0 && prim_id) *prim_id = c.first_id;
                 r = vadd(r, vscale(L, 1.0 / samps));
             }
@@ -646,6 +712,7 @@ static void render_pixel(const oscene *sc, const ocamera *cam, const oparams *pr
 typedef struct {
     const oscene *sc; const ocamera *cam; const oparams *pr; int x0, y0, rows, cols;
     double *rgb; int *prim_id; int next_row; pthread_mutex_t mu; ostats st;
+    int *lights; int n_lights;
 } job_t;
 
 static void *worker(void *arg) {
@@ -659,7 +726,7 @@ static void *worker(void *arg) {
         pthread_mutex_unlock(&j->mu);
         if (k0 >= npix) break;
         for (int k = k0; k < k0 + chunk && k < npix; k++)
-            render_pixel(j->sc, j->cam, j->pr, j->x0 + k / j->cols, j->y0 + k % j->cols, j->rgb + 3 * (size_t)k,
+            render_pixel(j->sc, j->cam, j->pr, j->lights, j->n_lights, j->x0 + k / j->cols, j->y0 + k % j->cols, j->rgb + 3 * (size_t)k,
                          j->prim_id ? j->prim_id + k : NULL, &st);
     }
     pthread_mutex_lock(&j->mu);
@@ -673,6 +740,7 @@ void orc_render_tile(const oscene *sc, const ocamera *cam, const oparams *pr, in
                      double *rgb, int *prim_id, ostats *st_out, int nthreads) {
     job_t j; memset(&j, 0, sizeof(j));
     j.sc = sc; j.cam = cam; j.pr = pr; j.x0 = x0; j.y0 = y0; j.rows = rows; j.cols = cols; j.rgb = rgb; j.prim_id = prim_id;
+    j.lights = light_list(sc, &j.n_lights);
     pthread_mutex_init(&j.mu, NULL);
     if (nthreads <= 1) worker(&j);
     else {
@@ -682,19 +750,23 @@ void orc_render_tile(const oscene *sc, const ocamera *cam, const oparams *pr, in
         free(th);
     }
     pthread_mutex_destroy(&j.mu);
+    free(j.lights);
     if (st_out) *st_out = j.st;
 }
 
 /* radiance() for explicit rays, each with its own restarted stream (path id = index). */
 void orc_radiance(const oscene *sc, const oparams *pr, int n, const double *rays, double *rgb, ostats *st_out) {
     octx c; c.sc = sc; c.pr = pr; memset(&c.st, 0, sizeof(c.st));
+    int nl = 0, *lights = light_list(sc, &nl);
+    c.lights = lights; c.n_lights = nl;
     for (int i = 0; i < n; i++) {
         ray_t r = {V(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), V(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5])};
         c.rng.x = path_state(pr->seed, (uint64_t)i);
         c.nrays_path = 0;
-        v3 L = radiance(&c, r, 0, 1);
+        v3 L = radiance(&c, r, 0, 1, 1, -1);
         rgb[3 * i] = L.x; rgb[3 * i + 1] = L.y; rgb[3 * i + 2] = L.z;
     }
+    free(lights);
     if (st_out) *st_out = c.st;
 }
 

@@ -43,7 +43,8 @@ class Tile(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("samps", C.c_int32), ("rr_depth", C.c_int32), ("rr_mode", C.c_int32), ("split_depth", C.c_int32),
-                ("hard_depth", C.c_int32), ("jitter", C.c_int32), ("seed", C.c_uint64)]
+                ("hard_depth", C.c_int32), ("jitter", C.c_int32), ("seed", C.c_uint64), ("light_mode", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -171,5 +172,5 @@ def make_camera(o, d, sizex, sizey):
     return cam
 
 
-def make_params(samps=1, rr_depth=5, rr_mode=1, split_depth=2, hard_depth=64, jitter=1, seed=1):
-    return Params(int(samps), int(rr_depth), int(rr_mode), int(split_depth), int(hard_depth), int(jitter), int(seed))
+def make_params(samps=1, rr_depth=5, rr_mode=1, split_depth=2, hard_depth=64, jitter=1, seed=1, light_mode=0):
+    return Params(int(samps), int(rr_depth), int(rr_mode), int(split_depth), int(hard_depth), int(jitter), int(seed), int(light_mode), 0)

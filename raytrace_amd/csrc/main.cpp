@@ -9,7 +9,8 @@
 // grouped RCCL exchange (include/rt_gather.h), and the OpenCV window is gone (output is headless).
 //
 // usage: raytrace_hip [scene.txt] [-o output.bmp] [--samps N] [--depth N] [--rr 0|1] [--seed N]
-//                     [--gpus N] [--tile N] [--gather rccl|copy] [--obj-flags N]
+//                     [--gpus N] [--tile N] [--gather rccl|copy] [--obj-flags N] [--lights 0|1]
+//   --lights 1      explicit light sampling (rt_params.light_mode; the reference has no such mode)
 //   --gather copy   collects the shares with one device-to-host copy per GPU instead of the RCCL exchange
 //   --obj-flags     RTH_OBJ_* bits for the OBJ reader (1: triangulate polygons, 2: negative indices)
 #include <hip/hip_runtime.h>
@@ -51,6 +52,7 @@ int main(int argc, char **argv) {
     std::string scene_path = "test.txt", out_path = "output.bmp"; // raytrace.cpp:106, 234
     int samps = -1, depth = 5, rr = 1, gpus = -1, tile = 64;
     unsigned obj_flags = 0;
+    int light_mode = 0;
     bool use_rccl = true;
     unsigned long long seed = 1;
     for (int i = 1; i < argc; i++) {
@@ -68,6 +70,7 @@ int main(int argc, char **argv) {
         else if (a == "--tile") tile = atoi(next("--tile"));
         else if (a == "--gather") use_rccl = std::string(next("--gather")) != "copy";
         else if (a == "--obj-flags") obj_flags = (unsigned)atoi(next("--obj-flags"));
+        else if (a == "--lights") light_mode = atoi(next("--lights"));
         else scene_path = a;
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -88,7 +91,7 @@ int main(int argc, char **argv) {
     rt_camera cam;
     for (int k = 0; k < 3; k++) { cam.o[k] = st.view[k]; cam.d[k] = st.dir[k]; }
     cam.sizex = st.sizex; cam.sizey = st.sizey;
-    rt_params prm = {samps, depth, rr, 2, 100000, 1, seed};
+    rt_params prm = {samps, depth, rr, 2, 100000, 1, seed, light_mode, 0};
 
     std::vector<rt_tile> tiles;
     for (int x0 = 0; x0 < st.sizex; x0 += tile)

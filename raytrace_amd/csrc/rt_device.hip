@@ -217,6 +217,8 @@ struct ColdArgs {
     const SphGeom *sph;
     const SphShade *sshade;
     const unsigned char *tex; // texture block (see TexTri), NULL without textures
+    const int *lights;        // indices of the emissive spheres, ascending (explicit light sampling)
+    int n_lights, pad_l;
     double cen[3]; // centre of the scene's vertex box
     double reach;  // its summed half extents + the scene's longest triangle edge
     double absn;   // |centre|_1 + summed half extents
@@ -459,16 +461,20 @@ enum { ST_RAYS = 0, ST_VISITS, ST_TRIS, ST_SPHS, ST_SHADES, ST_DONE, ST_CULLS, S
 // Words of a ray slot's state kept in HBM (8 bytes each, [word][slot] so lanes coalesce): what
 // only the shading step touches, plus the ray direction (read together with a record).
 //   LS_PST  low: depth (bits 0-19), pending branches (20-22), sub-pixel (23-24), into (25),
-//           primary (26), a traversal is waiting to be shaded (27); high: sample index
+//           primary (26), a traversal is waiting to be shaded (27), an emissive sphere at the hit adds its
+//           emission (28), the ray is a shadow ray (29), only sphere LS_COL adds its emission, times the
+//           number of lights (30); high: sample index
 //   LS_OUT  low: index in the packed output (render) / ray index (trace); high: pixel x << 16 | y
-//   LS_PEND parked glass branches, PEND_WORDS each: origin, direction, throughput, depth | into << 32
+//   LS_PEND parked rays (a glass hit's reflection; with light sampling, the bounce ray while the shadow ray is traced),
+//           PEND_WORDS each: origin, direction, throughput, depth | into << 32 | no sphere emission << 33
+//   LS_COL  the sphere a shadow ray was aimed at / the light a bounce ray stands in for (bit 30 above)
 //   LS_V    ray direction;  LS_BT best distance so far
 //   LS_HA   low: best triangle (TriShade index)
 //   LS_ST   nearest sphere's distance, LS_SI its index (-1 none, -2: not searched through the hierarchy)
 enum { LS_ACC = 0, LS_THR = 3, LS_RSUM = 6, LS_COL = 9, LS_RNG = 12, LS_PST = 13, LS_OUT = 14, LS_V = 15, LS_BT = 18, LS_HA = 19,
        LS_ST = 20, LS_SI = 21, LS_PEND = 22 };
 constexpr int PEND_WORDS = 10;
-constexpr int LS_WORDS = LS_PEND + PEND_WORDS * MAX_SPLIT;
+constexpr int LS_WORDS = LS_PEND + PEND_WORDS * (MAX_SPLIT + 1); // (+ 1: a bounce ray waiting for its shadow ray)
 // per-slot flags word in LDS: stack depth (bits 0-7), the frame's "has a hit" flag (8), the frame's
 // number of far children that are only counted (9-11), number of stack levels that live in HBM only (12-19), "the ray
 // starts far outside the scene" (20)
@@ -517,12 +523,14 @@ __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30
 
 // SPH = true: the scene has a sphere hierarchy (a second instance, so that scenes without one do not pay for it).
 // SLOTS, LDS_STACK: see KernelCfg.
-// TEX = true: the scene has textured triangles (an instance of its own, like SPH).
-template <bool TRACE, bool SPH, bool TEX, int SLOTS, int LDS_STACK>
+// FEAT selects what the shade step can do beyond the reference's untextured integrator (instances of their own, like
+// SPH): 1 = textured triangles, 2 = those and explicit light sampling (rt_params.light_mode 1).
+template <bool TRACE, bool SPH, int FEAT, int SLOTS, int LDS_STACK>
 #ifndef RT_KALIGN
 #define RT_KALIGN 256
 #endif
 __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIGN))) void k_main(DevScene S, const ColdArgs *__restrict__ cold, unsigned long long *gstats) {
+    constexpr bool TEX = FEAT >= 1, NEE = !TRACE && FEAT >= 2;
     __shared__ double2 sA[SLOTS]; // origin x, y
     __shared__ double2 sB[SLOTS]; // origin z, 1/direction x
     __shared__ double2 sC[SLOTS]; // 1/direction y, z
@@ -1023,6 +1031,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                 int depth = (int)(pst & 0xFFFFF), np = (int)((pst >> 20) & 7), sub = (int)((pst >> 23) & 3);
                 bool into = (pst >> 25) & 1, primary = (pst >> 26) & 1;
                 const bool have_hit = (pst >> 27) & 1;
+                bool emit_ok = !NEE || ((pst >> 28) & 1), shadow = NEE && ((pst >> 29) & 1), emit_one = NEE && ((pst >> 30) & 1);
                 unsigned long long rng = 0;
                 if (!TRACE) rng = (unsigned long long)__double_as_longlong(ls[LS_RNG * lss]);
                 if (have_hit) {
@@ -1043,6 +1052,11 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                         as_global(C.sph_id)[outk] = fs ? ids : -1;
                         as_global(C.sph_t)[outk] = ts;
                         need_work = true;
+                    } else if (NEE && shadow) { // the light adds what was set aside for it if it is what the ray reaches first
+                        if (fs && (ts < to || !fo) && ids == (int)__double_as_longlong(ls[LS_COL * lss])) {
+                            ls[LS_ACC * lss] += ls[LS_THR * lss]; ls[(LS_ACC + 1) * lss] += ls[(LS_THR + 1) * lss];
+                            ls[(LS_ACC + 2) * lss] += ls[(LS_THR + 2) * lss];
+                        }
                     } else if (fo || fs) { // raytrace.cpp:48-67
                         d3 x, n, f, lig;
                         int type;
@@ -1052,7 +1066,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                             const SphShade sh = c_sshade[ids];
                             x = o + d * ts;
                             n = normv(x - mk(g.px, g.py, g.pz));
-                            f = ld3(sh.col); type = sh.type; lig = ld3(sh.lig);
+                            f = ld3(sh.col); type = sh.type; lig = emit_ok ? ld3(sh.lig) : mk(0, 0, 0);
+                            if (NEE && emit_one && ids == (int)__double_as_longlong(ls[LS_COL * lss])) lig = ld3(sh.lig) * (double)C.n_lights;
                             if (primary && sub == 0 && smp == 0 && prim) prim[outk] = -1 - ids;
                         } else { // getn() returns the face normal (polygon.h:67-69)
                             const TriShade *sh = c_tshade + tpos;
@@ -1088,6 +1103,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                         }
                         if (go_on) {
                             thr = mult(thr, f);
+                            emit_ok = true; emit_one = false;
                             if (type == RT_DIFF) { // raytrace.cpp:77-82
                                 const double r1 = 2 * M_PI * rng_next(rng), r2 = rng_next(rng), r2s = sqrt(r2);
                                 const d3 w = nl, u = normv(cross(fabs(w.x) > .1 ? mk(0, 1, 0) : mk(1, 0, 0), w)), vv = cross(w, u);
@@ -1095,6 +1111,43 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                                 sincos_2pi(r1, sn, cs);
                                 rd = normv(u * cs * r2s + vv * sn * r2s + w * sqrt(1 - r2));
                                 ro = x - d * EPS;
+                                if (NEE) { // one emissive sphere, picked uniformly, sampled over the cone it subtends from ro
+                                    const int nlt = C.n_lights;
+                                    const double uk = rng_next(rng), eps1 = rng_next(rng), eps2 = rng_next(rng);
+                                    int k = (int)(uk * nlt);
+                                    k = k > nlt - 1 ? nlt - 1 : k;
+                                    const int target = as_global(C.lights)[k];
+                                    const SphGeom g = c_sph[target];
+                                    const d3 sv0 = mk(g.px, g.py, g.pz) - ro;
+                                    const double dist2 = dot(sv0, sv0), rad2 = g.rad * g.rad;
+                                    emit_ok = false;
+                                    if (!(dist2 > rad2)) { // inside the light: the bounce ray stands in for the sample
+                                        emit_one = true;
+                                        ls[LS_COL * lss] = __longlong_as_double((long long)target);
+                                    } else {
+                                        const d3 sw = sv0 * (1 / sqrt(dist2));
+                                        const d3 su = normv(cross(fabs(sw.x) > .1 ? mk(0, 1, 0) : mk(1, 0, 0), sw)), sv = cross(sw, su);
+                                        const double cos_a_max = sqrt(1 - rad2 / dist2);
+                                        const double cos_a = 1 - eps1 + eps1 * cos_a_max, sin_a = sqrt(1 - cos_a * cos_a);
+                                        double sp2, cp2;
+                                        sincos_2pi(2 * M_PI * eps2, sp2, cp2);
+                                        const d3 l = normv(su * cp2 * sin_a + sv * sp2 * sin_a + sw * cos_a);
+                                        const double cosl = dot(l, nl);
+                                        if (cosl > 0) { // park the bounce ray, trace the shadow ray first
+                                            double *q = ls + (size_t)(LS_PEND + PEND_WORDS * np) * lss;
+                                            np++;
+                                            q[0] = ro.x; q[lss] = ro.y; q[2 * lss] = ro.z;
+                                            q[3 * lss] = rd.x; q[4 * lss] = rd.y; q[5 * lss] = rd.z;
+                                            q[6 * lss] = thr.x; q[7 * lss] = thr.y; q[8 * lss] = thr.z;
+                                            q[9 * lss] = __longlong_as_double((long long)((unsigned long long)(unsigned)depth | ((unsigned long long)into << 32) | (1ull << 33)));
+                                            const double omega = 2 * M_PI * (1 - cos_a_max);
+                                            thr = mult(thr, ld3(c_sshade[target].lig)) * (cosl * omega * M_1_PI * nlt);
+                                            rd = l;
+                                            shadow = true;
+                                            ls[LS_COL * lss] = __longlong_as_double((long long)target);
+                                        }
+                                    }
+                                }
                             } else if (type == RT_SPEC) { // raytrace.cpp:83-84
                                 rd = d - n * 2.0 * dot(n, d);
                                 ro = x - d * EPS;
@@ -1135,7 +1188,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                             ro = mk(q[0], q[lss], q[2 * lss]); rd = mk(q[3 * lss], q[4 * lss], q[5 * lss]);
                             ls[LS_THR * lss] = q[6 * lss]; ls[(LS_THR + 1) * lss] = q[7 * lss]; ls[(LS_THR + 2) * lss] = q[8 * lss];
                             const unsigned long long w = (unsigned long long)__double_as_longlong(q[9 * lss]);
-                            depth = (int)(unsigned)w; into = (w >> 32) != 0;
+                            depth = (int)(unsigned)w; into = ((w >> 32) & 1) != 0;
+                            emit_ok = !NEE || ((w >> 33) & 1) == 0; shadow = false; emit_one = false;
                             go_on = true;
                         } else { // the path is complete (raytrace.cpp:203-205)
                             const double is = 1.0 / samps;
@@ -1230,11 +1284,12 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                     ls[LS_ACC * lss] = 0; ls[(LS_ACC + 1) * lss] = 0; ls[(LS_ACC + 2) * lss] = 0;
                     ls[LS_THR * lss] = 1; ls[(LS_THR + 1) * lss] = 1; ls[(LS_THR + 2) * lss] = 1;
                     depth = 0; into = true; np = 0; primary = true;
+                    emit_ok = true; shadow = false; emit_one = false;
                     go_on = true;
                 }
                 if (!TRACE) ls[LS_RNG * lss] = __longlong_as_double((long long)rng);
                 const unsigned npst = (unsigned)depth | ((unsigned)np << 20) | ((unsigned)sub << 23) | ((unsigned)into << 25) |
-                                      ((unsigned)primary << 26) | ((unsigned)go_on << 27);
+                                      ((unsigned)primary << 26) | ((unsigned)go_on << 27) | (NEE ? ((unsigned)emit_ok << 28) | ((unsigned)shadow << 29) | ((unsigned)emit_one << 30) : 0u);
                 ls[LS_PST * lss] = __longlong_as_double((long long)((unsigned long long)npst | ((unsigned long long)(unsigned)smp << 32)));
                 ls[LS_OUT * lss] = __longlong_as_double((long long)((unsigned long long)outk | ((unsigned long long)pxy << 32)));
                 if (go_on) { // KdTree::check on the root (raytrace.cpp:46)
@@ -1409,9 +1464,9 @@ struct rt_scene {
     ColdArgs cold{};            // the scene's part of the cold arguments (shading records, scene extent)
     ColdArgs *d_cold = nullptr; // where a launch's cold arguments go
     void *pool = nullptr, *tshade = nullptr, *tlist = nullptr, *sph = nullptr, *sshade = nullptr, *tex = nullptr;
-    void *ovf = nullptr, *lstate = nullptr, *lhdr = nullptr;
+    void *ovf = nullptr, *lstate = nullptr, *lhdr = nullptr, *lights = nullptr;
     int tree_depth = 0;
-    int grid = 0, grid_trace = 0; // persistent workgroups of the render / explicit-ray kernel
+    int grid = 0, grid_trace = 0, grid_lights = 0; // persistent workgroups of the render / explicit-ray / light-sampling kernel
     unsigned *d_counter = nullptr; // [0] block counter
     unsigned long long *d_stats = nullptr;
     int *d_blk_tile = nullptr; // tile of every 8x8 block of the current tile list
@@ -1437,18 +1492,19 @@ struct rt_scene {
 };
 
 using KernelFn = void (*)(DevScene, const ColdArgs *, unsigned long long *);
-template <bool TRACE, bool TEX>
+template <bool TRACE, int FEAT>
 KernelFn pick_kernel2(bool sph, bool deep) {
-    if (deep) return sph ? k_main<TRACE, true, TEX, CFG_DEEP.slots, CFG_DEEP.ring> : k_main<TRACE, false, TEX, CFG_DEEP.slots, CFG_DEEP.ring>;
-    return sph ? k_main<TRACE, true, TEX, CFG_SHALLOW.slots, CFG_SHALLOW.ring> : k_main<TRACE, false, TEX, CFG_SHALLOW.slots, CFG_SHALLOW.ring>;
+    if (deep) return sph ? k_main<TRACE, true, FEAT, CFG_DEEP.slots, CFG_DEEP.ring> : k_main<TRACE, false, FEAT, CFG_DEEP.slots, CFG_DEEP.ring>;
+    return sph ? k_main<TRACE, true, FEAT, CFG_SHALLOW.slots, CFG_SHALLOW.ring> : k_main<TRACE, false, FEAT, CFG_SHALLOW.slots, CFG_SHALLOW.ring>;
 }
-// (explicit-ray queries never shade: they have no textured instance)
+// (explicit-ray queries never shade: they have only the plain instance)
 template <bool TRACE>
-KernelFn pick_kernel(bool sph, bool deep, bool tex) {
-#ifndef RT_NO_TEX // (experiment builds without the textured instances)
-    if (!TRACE && tex) return pick_kernel2<false, true>(sph, deep);
+KernelFn pick_kernel(bool sph, bool deep, bool tex, bool lights = false) {
+#ifndef RT_NO_TEX // (experiment builds without the textured and light-sampling instances)
+    if (!TRACE && lights) return pick_kernel2<false, 2>(sph, deep);
+    if (!TRACE && tex) return pick_kernel2<false, 1>(sph, deep);
 #endif
-    return pick_kernel2<TRACE, false>(sph, deep);
+    return pick_kernel2<TRACE, 0>(sph, deep);
 }
 
 namespace {
@@ -1785,7 +1841,15 @@ int check_params(const rt_camera *cam, const rt_params *p) {
     if (p->split_depth < 0 || p->split_depth > MAX_SPLIT) return fail(RT_E_LIMIT, "split_depth must be in [0,%d]", MAX_SPLIT);
     if (p->rr_depth < 0) return fail(RT_E_INVALID, "rr_depth must be >= 0");
     if (p->hard_depth < 1 || p->hard_depth > 100000) return fail(RT_E_INVALID, "hard_depth must be in [1,100000]");
+    if (p->light_mode != 0 && p->light_mode != 1) return fail(RT_E_INVALID, "light_mode must be 0 or 1");
     return RT_OK;
+}
+
+// The render kernel for this scene and these controls, and the largest grid its state arrays allow.
+KernelFn render_kernel(const rt_scene *s, const rt_params *p, int *grid_cap) {
+    const bool lights = p->light_mode == 1 && s->cold.n_lights > 0; // (without emissive spheres the two modes are the same)
+    *grid_cap = lights ? s->grid_lights : s->grid;
+    return pick_kernel<false>(s->d.sph_root != 0, s->deep, s->cold.tex != nullptr, lights);
 }
 
 // raytrace.cpp:155-156
@@ -1896,9 +1960,10 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     HIP_TRY(hipMemsetAsync(s->d_subcnt, 0, (size_t)off * sizeof(unsigned), stream));
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, 16, stream));
     const DevCamera dc = make_camera(cam);
-    const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + s->slots - 1) / s->slots);
+    int grid_cap = 0;
+    const KernelFn kern = render_kernel(s, p, &grid_cap);
+    const int grid = (int)std::min<long long>(grid_cap, (blocks * 256 + s->slots - 1) / s->slots);
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep, s->cold.tex != nullptr);
     ColdArgs ca = s->cold;
     ca.cam = dc; ca.P = *p;
     ca.tiles = s->d_tiles; ca.blk_tile = s->d_blk_tile; ca.counter = s->d_counter;
@@ -2199,7 +2264,13 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     if (!rc) rc = upload(&s->sph, sg);
     if (!rc) rc = upload(&s->sshade, ss);
     if (!rc && n_textri) rc = upload(&s->tex, texblk);
+    std::vector<int> lights; // the emissive spheres (rt_params.light_mode 1 samples them)
+    for (int i = 0; i < D->n_spheres; i++)
+        if (ss[i].lig[0] != 0 || ss[i].lig[1] != 0 || ss[i].lig[2] != 0) lights.push_back(i);
+    if (!rc && !lights.empty()) rc = upload(&s->lights, lights);
     if (rc) { rt_free_scene(s); return rc; }
+    s->cold.lights = (const int *)s->lights;
+    s->cold.n_lights = (int)lights.size();
 
     int deep_from = DEEP_TREE;
     if (const char *e = getenv("RT_HIP_DEEP_TREE")) deep_from = atoi(e); // tuning / test knob: 0 = always the 8-level ring
@@ -2216,16 +2287,19 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
             return fail(RT_E_DEVICE, "hipGetDeviceProperties(%d): %s", dev, hipGetErrorString(pe));
         }
     }
-    // (the two instances this scene can run -- render and explicit rays -- each get the grid that fills the chip at
+    // (the instances this scene can run -- render, explicit rays, render with light sampling -- each get the grid that fills the chip at
     // their own occupancy; the per-slot state arrays are sized for the larger one)
-    int per_cu = 0, per_cu_t = 0;
+    int per_cu = 0, per_cu_t = 0, per_cu_l = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel<false>(sph_root != 0, s->deep, n_textri != 0), WAVE, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pick_kernel<true>(sph_root != 0, s->deep, false), WAVE, 0) != hipSuccess || per_cu_t < 1)
         per_cu_t = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, pick_kernel<false>(sph_root != 0, s->deep, n_textri != 0, true), WAVE, 0) != hipSuccess || per_cu_l < 1)
+        per_cu_l = 4;
     s->grid = pr.multiProcessorCount * per_cu;
     s->grid_trace = pr.multiProcessorCount * per_cu_t;
-    const int n_slots = std::max(s->grid, s->grid_trace) * slot_stride(s->slots);
+    s->grid_lights = pr.multiProcessorCount * per_cu_l;
+    const int n_slots = std::max(std::max(s->grid, s->grid_trace), s->grid_lights) * slot_stride(s->slots);
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
     const int need_depth = tree_depth + 3 * cull_depth + 5 + (sph_root ? 1 : 0);
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK + 1 : 0; // levels that can move to HBM
@@ -2292,7 +2366,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_cold, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile, s->d_stage_rgb, s->d_stage_prim};
+    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->lights, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_cold, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile, s->d_stage_rgb, s->d_stage_prim};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -2346,9 +2420,10 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
     hipLaunchKernelGGL(k_na_setup, dim3(1), dim3(256), 0, stream, T, scr);
     HIP_TRY(hipGetLastError());
     const DevCamera dc = make_camera(cam);
-    const int grid = (int)std::min<long long>(s->grid, (blocks * 256 + s->slots - 1) / s->slots);
+    int grid_cap = 0;
+    const KernelFn kern = render_kernel(s, p, &grid_cap);
+    const int grid = (int)std::min<long long>(grid_cap, (blocks * 256 + s->slots - 1) / s->slots);
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    const KernelFn kern = pick_kernel<false>(s->d.sph_root != 0, s->deep, s->cold.tex != nullptr);
     ColdArgs ca = s->cold;
     ca.cam = dc; ca.P = *p;
     ca.tiles = (const DevTile *)(scr + NA_OFF_TILES); ca.blk_tile = (const int *)(scr + NA_OFF_BLK); ca.counter = (unsigned *)(scr + NA_OFF_COUNTER);
@@ -2458,7 +2533,7 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
         const int grid = (int)std::min<long long>(s->grid_trace, want); // stay within the slot count the state arrays were sized for
         const KernelFn kern = pick_kernel<true>(s->d.sph_root != 0, s->deep, false);
         ColdArgs ca = s->cold;
-        ca.P = rt_params{1, 0, 0, 0, 1, 0, 0};
+        ca.P = rt_params{1, 0, 0, 0, 1, 0, 0, 0, 0};
         ca.counter = s->d_counter; ca.n_work = (unsigned)n;
         ca.rays = d_rays; ca.tri_id = d_ti; ca.tri_t = d_tt; ca.sph_id = d_si; ca.sph_t = d_st;
         hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, nullptr, ca, s->d_cold);

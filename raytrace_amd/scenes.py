@@ -179,6 +179,25 @@ def cornell_demo(sizex=600, sizey=800, mesh_bands=22, mesh_segs=24):
             "sizex": sizex, "sizey": sizey}
 
 
+def lamp_room(sizex=48, sizey=64, dome=True, lamp_rad=5.0):
+    """The Cornell box with its ceiling light replaced by a lamp hanging inside the room (the scene smallpt's
+    explicit-light-sampling variant uses), a second, dimmer lamp near the floor, the demo's glass cube and blob,
+    and -- with `dome` -- an emissive sphere around everything with the front wall taken out: every shaded
+    point is INSIDE that light, which therefore cannot be sampled over a cone."""
+    sp = _cornell_spheres()[:8]
+    if dome:
+        del sp[3]  # the front wall: the dome is seen through the opening
+    sp.append(_sphere(lamp_rad, (50, 81.6 - 16.5, 81.6), (40, 40, 40), (0, 0, 0), DIFF))
+    sp.append(_sphere(3.0, (80, 6, 120), (6, 14, 20), (0, 0, 0), DIFF))
+    if dome:
+        sp.append(_sphere(3e5, (50, 40, 80), (.35, .4, .5), (0, 0, 0), DIFF))
+    cube = translate(rotate(box((-7, -7, -7), (7, 7, 7)), (0, 30, 0)), (52, 7.01, 112))
+    bl = blob((28, 11, 100), 8.0, 10, 12, seed=7, amp=0.5)
+    return {"name": "lamp_room" + ("_dome" if dome else ""), "meshes": [_mesh(cube, (.999, .999, .999), REFR), _mesh(bl, (.85, .75, .2), DIFF)],
+            "spheres": sp, "camera": {"o": np.array([50, 52, 295.6]), "d": np.array([0, -0.042612, -1.0])},
+            "sizex": sizex, "sizey": sizey}
+
+
 def _blob_counts(n_body):
     bands = max(3, int(round(math.sqrt(n_body / 4.0))))
     segs = max(3, (n_body - 3) // (2 * (bands - 1)))
