@@ -84,6 +84,9 @@ constexpr int slot_stride(int slots) { return (slots + 31) & ~31; }
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 #ifdef RT_PROFILE
 constexpr int N_STATS = 25; // 11..20: clock ticks in vote, the four bodies, tail; steps per kind; 21..24: triangle step details
+#elif defined(RT_EVENTS)
+constexpr int N_EVENTS = 20;
+constexpr int N_STATS = 11 + 2 * N_EVENTS; // 11..: per event, the steps in which some lane met it, and the lanes that did
 #else
 constexpr int N_STATS = 11;
 #endif
@@ -599,8 +602,20 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
 #else
 #define RT_TICK(x)
 #endif
+#ifdef RT_EVENTS // how often the loop's side paths run: steps with at least one such lane, and lanes
+    unsigned long long p_ev[N_EVENTS] = {}, p_evl[N_EVENTS] = {};
+#define RT_EV(k, cond) do { const unsigned long long b_ = __ballot(cond); p_ev[k] += b_ != 0; p_evl[k] += __popcll(b_); } while (0)
+#else
+#define RT_EV(k, cond)
+#endif
+#ifdef RT_MARKS // comments in the assembly at the borders of the loop's parts (for reading it; no effect on the code)
+#define RT_MARK(name) asm volatile("; RTMARK " name)
+#else
+#define RT_MARK(name)
+#endif
     for (;;) {
         RT_TICK(tk0);
+        RT_MARK("pick");
         // ---- vote: run the kind most slots wait for; its (up to 64) topmost entries go to the lanes
         asm("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3)); // keep the counts in scalar registers
         int pick = K_NODE, most = q0;
@@ -658,8 +673,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
         unsigned push_item = 0; // item to push before that (0 = none; the root is never pushed)
         bool done = false;      // the slot found no more work
         RT_TICK(tk1);
+        RT_MARK("bodies");
 
         if (pick == K_NODE) {
+            RT_MARK("node");
             const bool refill = run && cur == IT_REFILL;
             const bool marker = run && is_marker(cur); // a second marker in a row (see the tail)
             if (marker) want_pop = do_marker(cur);
@@ -672,6 +689,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                 }
             }
             bool skipped = false, skipped_far = false; // a child's visit was decided here (it is still a visit of the reference)
+            bool ev_exact = false, ev_fail = false;
             if (run && !refill && !marker) { // ---- enter a node (kdtree.cpp:111-141)
                 const double2 *p = (const double2 *)(S.pool + (size_t)cur * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
@@ -714,12 +732,14 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                 const double iw = axis == 0 ? inv[0] : axis == 1 ? inv[1] : inv[2];
                 bool pass = inside | clear;
                 bool vpos = iw > 0, vneg = iw < 0; // sign of the direction along the split axis
+                ev_exact = (maybe & !pass) | (fabs(iw) >= 1e299);
                 if ((maybe & !pass) | (fabs(iw) >= 1e299)) { // rare: needs the direction itself
                     const double v[3] = {ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]};
                     if (!pass) pass = maybe && aabb_hit(mi, ma, s, v);
                     const double vw = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
                     vpos = vw > 0; vneg = vw < 0;
                 }
+                ev_fail = !pass;
                 if (!pass) want_pop = true;
                 else {
                     l_tris += info >> 3; // the own list will be scanned (kdtree.cpp:122,131,137)
@@ -814,10 +834,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                     if (sp - k >= 0) stk[(sp - k) & (LDS_STACK - 1)][slot] = rf[k];
                 slo = sp - (REFILL - 1) > 0 ? sp - (REFILL - 1) : 0;
             }
+            RT_EV(0, run && !refill && !marker); RT_EV(1, ev_exact); RT_EV(2, refill); RT_EV(3, marker); RT_EV(4, ev_fail);
+            RT_EV(16, run && !refill && !marker && !ev_fail && next != 0 && !want_pop && push_item == 0); // goes on without a push
             const int entered = nrun - (int)__popcll(__ballot(refill | marker)); // lanes that fetched a node's records
             RT_SCOUNT(c_nfetch, entered);
             RT_SCOUNT(c_visits, entered + (int)__popcll(__ballot(skipped)) + (int)__popcll(__ballot(skipped_far)));
         } else if (pick == K_CULL) {
+            RT_MARK("cull");
             bool boxes = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
                 const unsigned g = (cur & IT_AFTER) ? S.g_list + after_granule(cur) : (cur & IDX28);
@@ -942,8 +965,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                     }
                 }
             }
+            RT_EV(5, run && (cur & IT_AFTER)); RT_EV(6, boxes); RT_EV(7, boxes && want_pop); RT_EV(8, run && !boxes);
             RT_SCOUNT(c_culls, (unsigned)__popcll(__ballot(boxes)));
         } else if (pick == K_TRI) {
+            RT_MARK("tri");
             bool is_sph = false;
             if (run) { // ---- one exact triangle test (kdtree.cpp:105)
                 const double2 *p = (const double2 *)(S.pool + (size_t)(cur & IDX28) * 16);
@@ -1002,10 +1027,12 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                 p_tri[3] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) == 0 && t > EPS)); // ... that hit
 #endif
             }
+            RT_EV(9, run); RT_EV(10, run && (st & ST_FLAG));
             const int nsph = (int)__popcll(__ballot(is_sph));
             RT_SCOUNT(c_done, nrun - nsph);
             RT_SCOUNT(c_sphdone, nsph);
         } else {
+            RT_MARK("shade");
             bool ev_ray = false, ev_shade = false, ev_scan = false;
             if (run) { // ---- traversal finished (or nothing started yet)
                 // the launch's cold arguments, read here and nowhere else
@@ -1325,11 +1352,15 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
 
         // ---- common tail for the lanes that ran: push, pop, publish the slot's next item
         RT_TICK(tk2);
+        RT_MARK("tail");
+        RT_EV(11, run && push_item != 0); RT_EV(12, run && push_item != 0 && sp - slo == LDS_STACK); RT_EV(13, run && want_pop);
+        RT_EV(17, run && want_pop && sp <= slo && sp != 0); // the popped level is in HBM
         if (run) {
             if (push_item != 0) push(push_item);
             // Pop; a marker (see the node step: "the near subtree is done and there is no own list to scan") that
             // comes up is dealt with on the spot, one per tail -- a second one in a row goes through a node step.
             if (want_pop) next = pop();
+            RT_EV(14, is_marker(next)); RT_EV(15, next == IT_END);
             if (is_marker(next)) { // (without inner branches: the level below is read whether or not it is taken)
                 const unsigned m = next, fk = (m >> 28) & 3u;
                 const bool near_hit = (st & ST_FLAG) != 0, take_far = !near_hit && (fk == 1u || fk == 2u);
@@ -1372,6 +1403,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
     }
 #endif
 
+#ifdef RT_EVENTS
+    if (lane == 0)
+        for (int k = 0; k < N_EVENTS; k++) { atomicAdd(gstats + 11 + 2 * k, p_ev[k]); atomicAdd(gstats + 12 + 2 * k, p_evl[k]); }
+#endif
     // ---- work counters
     flush();
     for (int off = 32; off > 0; off >>= 1) l_tris += __shfl_down(l_tris, off, 64);
@@ -2449,6 +2484,19 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
     stats->rays = h[0]; stats->node_visits = h[1]; stats->tri_tests = h[2]; stats->sph_tests = h[3]; stats->tri_shades = h[4];
     stats->tri_tests_done = h[5]; stats->cull_tests = h[6]; stats->sched_steps = h[7]; stats->sched_lanes = h[8];
     stats->node_fetches = h[9]; stats->sph_tests_done = h[10];
+#ifdef RT_EVENTS
+    {
+        static const char *en[N_EVENTS] = {"node: record fetched", "node: exact check_aabb code", "node: refill", "node: marker", "node: box not met",
+                                           "cull: after item", "cull: boxes tested", "cull: no box met", "cull: short list / none", "tri: step",
+                                           "tri: frame has a hit", "tail: push", "tail: push moves a level to HBM", "tail: pop", "tail: marker popped",
+                                           "tail: traversal ends", "node: goes on without a push", "tail: popped level is in HBM", "", ""};
+        const double iters = (double)h[ST_ITERS], rays = (double)h[ST_RAYS];
+        for (int k = 0; k < N_EVENTS; k++)
+            if (en[k][0])
+                fprintf(stderr, "[events] %-34s steps %6.2f%% of all  lanes/ray %7.3f  lanes per such step %5.1f\n", en[k], 100.0 * h[11 + 2 * k] / iters,
+                        h[12 + 2 * k] / rays, h[11 + 2 * k] ? (double)h[12 + 2 * k] / h[11 + 2 * k] : 0.0);
+    }
+#endif
 #ifdef RT_PROFILE
     {
         static const char *kn[4] = {"node", "cull", "tri", "shade"};
