@@ -66,7 +66,9 @@ constexpr int WAVE = 64;          // threads per workgroup: one wavefront
 // plus 4 per ring level: 152 slots with a 4-level ring are the most that leave room for twelve wavefronts per CU, 140
 // with an 8-level ring for eleven.  With equally many wavefronts more slots mean fuller steps; a deep tree moves too
 // many levels through HBM with the short ring.  RT_SLOTS / RT_LDS_STACK make both builds the same (test builds).
-struct KernelCfg { int slots, ring; };
+// (Workgroups of two wavefronts could share 21 pieces, 159 slots each: 0.92 instead of 0.90 of the lanes busy per step,
+// but the same kernel runs 2 % slower in workgroups of two at equal slot count -- measured, no gain; RT_WPG keeps the option.)
+struct KernelCfg { int slots, ring, wpg; }; // wpg: wavefronts per workgroup (each with its own slots; they share nothing)
 #if defined(RT_SLOTS) || defined(RT_LDS_STACK)
 #ifndef RT_SLOTS
 #define RT_SLOTS 140
@@ -74,9 +76,12 @@ struct KernelCfg { int slots, ring; };
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK 8
 #endif
-constexpr KernelCfg CFG_SHALLOW = {RT_SLOTS, RT_LDS_STACK}, CFG_DEEP = {RT_SLOTS, RT_LDS_STACK};
+#ifndef RT_WPG
+#define RT_WPG 1
+#endif
+constexpr KernelCfg CFG_SHALLOW = {RT_SLOTS, RT_LDS_STACK, RT_WPG}, CFG_DEEP = {RT_SLOTS, RT_LDS_STACK, RT_WPG};
 #else
-constexpr KernelCfg CFG_SHALLOW = {152, 4}, CFG_DEEP = {140, 8};
+constexpr KernelCfg CFG_SHALLOW = {152, 4, 1}, CFG_DEEP = {140, 8, 1};
 #endif
 constexpr int DEEP_TREE = 28; // tree depth from which the 8-level ring is used
 // a wavefront's slots in the per-slot arrays in HBM: whole 128-byte lines, so that no two wavefronts write one line
@@ -528,33 +533,36 @@ __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30
 // SLOTS, LDS_STACK: see KernelCfg.
 // FEAT selects what the shade step can do beyond the reference's untextured integrator (instances of their own, like
 // SPH): 1 = textured triangles, 2 = those and explicit light sampling (rt_params.light_mode 1).
-template <bool TRACE, bool SPH, int FEAT, int SLOTS, int LDS_STACK>
+template <bool TRACE, bool SPH, int FEAT, int SLOTS, int LDS_STACK, int WPG>
 #ifndef RT_KALIGN
 #define RT_KALIGN 256
 #endif
-__global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIGN))) void k_main(DevScene S, const ColdArgs *__restrict__ cold, unsigned long long *gstats) {
+__global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT_KALIGN))) void k_main(DevScene S, const ColdArgs *__restrict__ cold, unsigned long long *gstats) {
     constexpr bool TEX = FEAT >= 1, NEE = !TRACE && FEAT >= 2;
-    __shared__ double2 sA[SLOTS]; // origin x, y
-    __shared__ double2 sB[SLOTS]; // origin z, 1/direction x
-    __shared__ double2 sC[SLOTS]; // 1/direction y, z
+    __shared__ double2 sA[WPG * SLOTS]; // origin x, y
+    __shared__ double2 sB[WPG * SLOTS]; // origin z, 1/direction x
+    __shared__ double2 sC[WPG * SLOTS]; // 1/direction y, z
     // (both kept as the upper half of a float with the magnitude rounded up: a larger margin only culls less)
-    __shared__ unsigned char sM[SLOTS]; // inflation of the current list's culling boxes
-    __shared__ unsigned char sG[SLOTS]; // the ray's margin factor (ST_FAR in the flags word: beyond what the working coefficients cover)
-    __shared__ unsigned short sT[SLOTS]; // the best distance so far (triangles; the same 16-bit form, so never too small)
-    __shared__ unsigned stk[LDS_STACK][SLOTS];
+    __shared__ unsigned char sM[WPG * SLOTS]; // inflation of the current list's culling boxes
+    __shared__ unsigned char sG[WPG * SLOTS]; // the ray's margin factor (ST_FAR in the flags word: beyond what the working coefficients cover)
+    __shared__ unsigned short sT[WPG * SLOTS]; // the best distance so far (triangles; the same 16-bit form, so never too small)
+    __shared__ unsigned stk[LDS_STACK][WPG * SLOTS];
     // the slots that wait for a step, one stack per kind: slot | flags word << 8; item.  Two stacks share an
     // array and grow towards each other (a slot is in at most one of them): node up from 0 and cull down from
     // SLOTS - 1, tri up from SLOTS and shade down from 2 * SLOTS - 1
-    __shared__ uint2 sQ[2 * SLOTS];
+    __shared__ uint2 sQ[WPG * 2 * SLOTS];
     constexpr int SLOT_STRIDE = slot_stride(SLOTS), REFILL = refill_levels(LDS_STACK);
     static_assert(SLOTS >= WAVE && SLOTS <= 256, "a slot index is kept in 8 bits");
     static_assert((LDS_STACK & (LDS_STACK - 1)) == 0 && REFILL >= 1 && REFILL - 1 <= LDS_STACK, "the refilled levels but the first go to the ring");
     static_assert(SLOT_STRIDE % 32 == 0 && SLOT_STRIDE >= SLOTS, "a wavefront's 4-byte columns of the HBM state start on a cache line");
-    const int lane = threadIdx.x;
+    // (a workgroup of WPG wavefronts is WPG independent copies of what follows: each has its own part of every array)
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = WPG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int wslot0 = wv * SLOTS; // this wavefront's first slot in the LDS arrays
     const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    auto qindex = [](int kind, int i) __attribute__((always_inline)) { return (kind >> 1) * SLOTS + ((kind & 1) ? SLOTS - 1 - i : i); };
+    auto qindex = [wslot0](int kind, int i) __attribute__((always_inline)) { return 2 * wslot0 + (kind >> 1) * SLOTS + ((kind & 1) ? SLOTS - 1 - i : i); };
     const size_t lss = (size_t)S.n_slots;
-    const unsigned gslot0 = blockIdx.x * SLOT_STRIDE;
+    const unsigned gslot0 = (blockIdx.x * WPG + wv) * SLOT_STRIDE;
 
     // all slots start as "nothing traced yet, needs work"
     for (int i = lane; i < SLOTS; i += WAVE) {
@@ -567,7 +575,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
     // (one lane writes what the others read, so the compiler must not keep a lane's old value: relaxed atomic
     // accesses -- a `volatile` array here is accessed through generic-address instructions, and one of those in
     // flight makes the compiler put a full wait before every LDS read that follows)
-    __shared__ unsigned sStash[2];
+    __shared__ unsigned sStashAll[WPG * 2];
+    unsigned *const sStash = sStashAll + 2 * wv;
     auto stash_get = [&](int i) __attribute__((always_inline)) { return __hip_atomic_load(&sStash[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto stash_put = [&](int i, unsigned v) __attribute__((always_inline)) { __hip_atomic_store(&sStash[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     if (lane == 0) { stash_put(0, 0u); stash_put(1, 0u); }
@@ -630,6 +639,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
         uint2 e = make_uint2(0u, 0u);
         if (run) e = sQ[qindex(pick, rest + lane)];
         const int slot = (int)(e.x & 0xFFu);
+        const int sl = slot + wslot0; // its index in the LDS arrays
         const unsigned cur = e.y;
         unsigned st = e.x >> 8;
         double *const ls = S.lstate + gslot0 + slot; // this slot's column of the HBM state
@@ -640,14 +650,14 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
         int sp = (int)(st & ST_SP), slo = (int)((st >> ST_LO) & 0xFFu);
         auto push = [&](unsigned item) __attribute__((always_inline)) {
             if (sp - slo == LDS_STACK) { // ring full: its oldest level moves to HBM
-                S.ovf[(unsigned)slo * (unsigned)S.n_slots + gslot0 + (unsigned)slot] = stk[slo & (LDS_STACK - 1)][slot];
+                S.ovf[(unsigned)slo * (unsigned)S.n_slots + gslot0 + (unsigned)slot] = stk[slo & (LDS_STACK - 1)][sl];
                 slo++;
             }
-            stk[sp & (LDS_STACK - 1)][slot] = item;
+            stk[sp & (LDS_STACK - 1)][sl] = item;
             sp++;
         };
         auto pop = [&]() __attribute__((always_inline)) -> unsigned { // (without branches: the read is harmless when not used)
-            const unsigned e = stk[(sp - 1) & (LDS_STACK - 1)][slot];
+            const unsigned e = stk[(sp - 1) & (LDS_STACK - 1)][sl];
             const bool in_ring = sp > slo;
             // the ring is empty: the level is in HBM and stays there until a refill step
             const unsigned r = sp == 0 ? IT_END : in_ring ? e : IT_REFILL;
@@ -695,8 +705,8 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 const uint4 *kp = (const uint4 *)(S.pool + (size_t)(2u * S.g_list + 3u * (cur >> 2)) * 16); // boxes of the children and the own list
                 const uint4 k0 = kp[0], k1 = kp[1], k2 = kp[2];
-                const float gfac = exp_up_get(sG[slot]);
-                const double2 a = sA[slot], b = sB[slot], c = sC[slot];
+                const float gfac = exp_up_get(sG[sl]);
+                const double2 a = sA[sl], b = sB[sl], c = sC[sl];
                 const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
                 const double mi[3] = {q0.x, q0.y, q1.x}, ma[3] = {q1.y, q2.x, q2.y};
                 const double split = q3.x;
@@ -831,7 +841,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                 next = rf[0];
 #pragma unroll
                 for (int k = 1; k < REFILL; k++)
-                    if (sp - k >= 0) stk[(sp - k) & (LDS_STACK - 1)][slot] = rf[k];
+                    if (sp - k >= 0) stk[(sp - k) & (LDS_STACK - 1)][sl] = rf[k];
                 slo = sp - (REFILL - 1) > 0 ? sp - (REFILL - 1) : 0;
             }
             RT_EV(0, run && !refill && !marker); RT_EV(1, ev_exact); RT_EV(2, refill); RT_EV(3, marker); RT_EV(4, ev_fail);
@@ -849,13 +859,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                 // right child, list header (every lane loads, the others node 0's: a load under a branch of its own
                 // makes the compiler wait for all of the loads above before it goes on)
                 const uint2 hdr = *(const uint2 *)(S.lhdr + ((cur & IT_AFTER) ? after_granule(cur) >> 2 : 0u));
-                const double2 a = sA[slot], b = sB[slot], c = sC[slot];
-                float mg = exp_up_get(sM[slot]);
+                const double2 a = sA[sl], b = sB[sl], c = sC[sl];
+                float mg = exp_up_get(sM[sl]);
                 // (for an after item the flag of the enclosing frame is restored below: st or the item's bit)
                 // (the sphere hierarchy keeps only the nearest sphere: its boxes are always limited by that distance)
                 const bool sph_boxes = SPH && !(cur & IT_AFTER) && (cur & IDX28) >= S.g_sphc;
                 const bool lim_on = sph_boxes || ((st & ST_FLAG) != 0) || ((cur & IT_AFTER) && ((cur >> 30) & 1));
-                float best_lim = half_up_get(sT[slot]);
+                float best_lim = half_up_get(sT[sl]);
                 if (sph_boxes) best_lim = (float)ls[LS_ST * lss];
                 boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
@@ -873,10 +883,10 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                         if ((meta & 0xFF) == 0) want_pop = true;
                         else next = it.x;
                     } else { // inflation of this list's boxes, see ray_margin_factor(); a larger one only culls less
-                        const float gfac = exp_up_get(sG[slot]);
+                        const float gfac = exp_up_get(sG[sl]);
                         // (the exponent in the low mantissa bits only makes the coefficient a little larger)
                         mg = ldexpf(__uint_as_float(meta), (st & ST_FAR) ? (int)(meta & 0xFFu) : 0) * gfac;
-                        { const unsigned char h = exp_up_put(mg); sM[slot] = h; mg = exp_up_get(h); }
+                        { const unsigned char h = exp_up_put(mg); sM[sl] = h; mg = exp_up_get(h); }
                     }
                 }
                 if (SPH && !(cur & IT_AFTER) && (cur & IT_CHAIN)) { // root of the sphere hierarchy: the kd-tree is done
@@ -886,7 +896,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                     const double gs = fabs(a.x - S.sph_cen[0]) + fabs(a.y - S.sph_cen[1]) + fabs(b.x - S.sph_cen[2]) + S.sph_h;
                     const float gsf = (float)gs * 1.000001f;
                     mg = S.sph_k * gsf * gsf + S.sph_c;
-                    { const unsigned char h = exp_up_put(mg); sM[slot] = h; mg = exp_up_get(h); }
+                    { const unsigned char h = exp_up_put(mg); sM[sl] = h; mg = exp_up_get(h); }
                 }
                 if (boxes) {
                     // Slab test of the four inflated boxes in single precision, two planes per packed
@@ -949,13 +959,13 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                                 if (over > 0) {
 #pragma unroll
                                     for (int k = 0; k < 3; k++)
-                                        if (k < over) S.ovf[(unsigned)(slo + k) * (unsigned)S.n_slots + gslot0 + (unsigned)slot] = stk[(slo + k) & (LDS_STACK - 1)][slot];
+                                        if (k < over) S.ovf[(unsigned)(slo + k) * (unsigned)S.n_slots + gslot0 + (unsigned)slot] = stk[(slo + k) & (LDS_STACK - 1)][sl];
                                     slo += over;
                                 }
                             }
-                            if (hit[1] & (n1 > 0)) stk[(sp + n1 - 1) & (LDS_STACK - 1)][slot] = item[1];
-                            if (hit[2] & (n2 > 0)) stk[(sp + n2 - 1) & (LDS_STACK - 1)][slot] = item[2];
-                            if (hit[3] & (n3 > 0)) stk[(sp + n3 - 1) & (LDS_STACK - 1)][slot] = item[3];
+                            if (hit[1] & (n1 > 0)) stk[(sp + n1 - 1) & (LDS_STACK - 1)][sl] = item[1];
+                            if (hit[2] & (n2 > 0)) stk[(sp + n2 - 1) & (LDS_STACK - 1)][sl] = item[2];
+                            if (hit[3] & (n3 > 0)) stk[(sp + n3 - 1) & (LDS_STACK - 1)][sl] = item[3];
                             sp += n4 - 1;
                         } else {
                             if (hit[1] & (n1 > 0)) push(item[1]);
@@ -976,7 +986,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                 const long long w9 = __double_as_longlong(q4.y);
                 const d3 d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
                 const double best_t = ls[LS_BT * lss];
-                const double2 a = sA[slot], b = sB[slot];
+                const double2 a = sA[sl], b = sB[sl];
                 const d3 o = mk(a.x, a.y, b.x);
                 is_sph = SPH && (cur & IDX28) >= S.g_sph;
                 if (is_sph) { // ---- one sphere of the sphere hierarchy (sphere.h:13-21, sphere.cpp:7)
@@ -1012,7 +1022,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                     }
                     if (better) {
                         ls[LS_BT * lss] = t;
-                        sT[slot] = half_up_put((float)t * 1.000001f); // (t > 0; the factor covers the rounding to single)
+                        sT[sl] = half_up_put((float)t * 1.000001f); // (t > 0; the factor covers the rounding to single)
                         ls[LS_HA * lss] = __longlong_as_double((long long)(unsigned long long)((unsigned)w9 & ~TRI_LAST));
                     }
                     if (t < 1e10) st |= ST_FLAG;
@@ -1062,7 +1072,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                 unsigned long long rng = 0;
                 if (!TRACE) rng = (unsigned long long)__double_as_longlong(ls[LS_RNG * lss]);
                 if (have_hit) {
-                    const double2 a = sA[slot], b = sB[slot];
+                    const double2 a = sA[sl], b = sB[sl];
                     const d3 o = mk(a.x, a.y, b.x), d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
                     const double to = ls[LS_BT * lss];
                     const int tpos = (int)((const unsigned *)&ls[LS_HA * lss])[0];
@@ -1323,14 +1333,14 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                     const double ix = fabs(rd.x) < 1e-150 ? 1e300 : 1.0 / rd.x, iy = fabs(rd.y) < 1e-150 ? 1e300 : 1.0 / rd.y,
                                  iz = fabs(rd.z) < 1e-150 ? 1e300 : 1.0 / rd.z;
                     const float gf = ray_margin_factor(C.cen, C.reach, C.absn, ro.x, ro.y, ro.z, sqrt(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z));
-                    sA[slot] = make_double2(ro.x, ro.y);
-                    sB[slot] = make_double2(ro.z, ix);
-                    sC[slot] = make_double2(iy, iz);
+                    sA[sl] = make_double2(ro.x, ro.y);
+                    sB[sl] = make_double2(ro.z, ix);
+                    sC[sl] = make_double2(iy, iz);
                     ls[LS_V * lss] = rd.x; ls[(LS_V + 1) * lss] = rd.y; ls[(LS_V + 2) * lss] = rd.z;
                     ls[LS_BT * lss] = 1e20;
-                    sT[slot] = 0x7F80u; // infinity
+                    sT[sl] = 0x7F80u; // infinity
                     ls[LS_HA * lss] = __longlong_as_double(-1ll);                   // no triangle
-                    sG[slot] = exp_up_put(gf);
+                    sG[sl] = exp_up_put(gf);
                     // beyond the factor (4 * reach + 1 at upload) that the lists' working coefficients cover: the larger ones
                     st = gf <= (float)(3.9 * C.reach) ? 0u : ST_FAR;
                     sp = 0; slo = 0;
@@ -1338,7 +1348,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                         const bool unit = fabs(dot(rd, rd) - 1.0) <= 1e-12; // what the boxes' inflation assumes
                         ls[LS_ST * lss] = 1e20;
                         ls[LS_SI * lss] = __longlong_as_double(unit ? -1ll : -2ll);
-                        if (unit) { stk[0][slot] = S.sph_root; sp = 1; }
+                        if (unit) { stk[0][sl] = S.sph_root; sp = 1; }
                     }
                     ev_ray = true;
                     // next stays 0: the root node
@@ -1367,7 +1377,7 @@ __global__ __launch_bounds__(WAVE, RT_MIN_WAVES) __attribute__((aligned(RT_KALIG
                 vis_add += near_hit ? 0u : ((st >> ST_NSH) & 7u) + (fk == 3u ? 1u : 0u);
                 st = (st & ~ST_N) | (((m >> IT_NSH) & 7u) << ST_NSH);
                 st |= ((m >> 30) & 1u) << 8; // ST_FLAG: back in the enclosing frame
-                const unsigned e = stk[(sp - 1) & (LDS_STACK - 1)][slot];
+                const unsigned e = stk[(sp - 1) & (LDS_STACK - 1)][sl];
                 const bool in_ring = sp > slo;
                 next = take_far ? after_granule(m) : sp == 0 ? IT_END : in_ring ? e : IT_REFILL;
                 sp -= (!take_far && in_ring) ? 1 : 0;
@@ -1523,14 +1533,15 @@ struct rt_scene {
     bool timed = false;
     hipStream_t last_stream = nullptr;
     bool deep = false;           // which build of the kernel this scene runs (KernelCfg)
-    int slots = 0;               // its slots per workgroup
+    int slots = 0, wpg = 1;      // its slots per wavefront and wavefronts per workgroup
 };
 
 using KernelFn = void (*)(DevScene, const ColdArgs *, unsigned long long *);
 template <bool TRACE, int FEAT>
 KernelFn pick_kernel2(bool sph, bool deep) {
-    if (deep) return sph ? k_main<TRACE, true, FEAT, CFG_DEEP.slots, CFG_DEEP.ring> : k_main<TRACE, false, FEAT, CFG_DEEP.slots, CFG_DEEP.ring>;
-    return sph ? k_main<TRACE, true, FEAT, CFG_SHALLOW.slots, CFG_SHALLOW.ring> : k_main<TRACE, false, FEAT, CFG_SHALLOW.slots, CFG_SHALLOW.ring>;
+    if (deep) return sph ? k_main<TRACE, true, FEAT, CFG_DEEP.slots, CFG_DEEP.ring, CFG_DEEP.wpg> : k_main<TRACE, false, FEAT, CFG_DEEP.slots, CFG_DEEP.ring, CFG_DEEP.wpg>;
+    return sph ? k_main<TRACE, true, FEAT, CFG_SHALLOW.slots, CFG_SHALLOW.ring, CFG_SHALLOW.wpg>
+               : k_main<TRACE, false, FEAT, CFG_SHALLOW.slots, CFG_SHALLOW.ring, CFG_SHALLOW.wpg>;
 }
 // (explicit-ray queries never shade: they have only the plain instance)
 template <bool TRACE>
@@ -1997,7 +2008,7 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     const DevCamera dc = make_camera(cam);
     int grid_cap = 0;
     const KernelFn kern = render_kernel(s, p, &grid_cap);
-    const int grid = (int)std::min<long long>(grid_cap, (blocks * 256 + s->slots - 1) / s->slots);
+    const int grid = (int)std::min<long long>(grid_cap, (blocks * 256 + s->slots * s->wpg - 1) / (s->slots * s->wpg));
     HIP_TRY(hipEventRecord(s->ev0, stream));
     ColdArgs ca = s->cold;
     ca.cam = dc; ca.P = *p;
@@ -2006,7 +2017,7 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     ca.n_work = (unsigned)(blocks * 256); ca.n_tiles = n_tiles;
     hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, stream, ca, s->d_cold);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, (const ColdArgs *)s->d_cold, s->d_stats);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, stream, s->d, (const ColdArgs *)s->d_cold, s->d_stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     s->timed = true;
@@ -2312,6 +2323,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->deep = tree_depth >= deep_from;
     const KernelCfg cfg = s->deep ? CFG_DEEP : CFG_SHALLOW;
     s->slots = cfg.slots;
+    s->wpg = cfg.wpg;
     const int LDS_STACK = cfg.ring;
     // persistent grid: as many workgroups as the chip holds at this kernel's occupancy
     hipDeviceProp_t pr;
@@ -2325,16 +2337,16 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     // (the instances this scene can run -- render, explicit rays, render with light sampling -- each get the grid that fills the chip at
     // their own occupancy; the per-slot state arrays are sized for the larger one)
     int per_cu = 0, per_cu_t = 0, per_cu_l = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel<false>(sph_root != 0, s->deep, n_textri != 0), WAVE, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel<false>(sph_root != 0, s->deep, n_textri != 0), WAVE * cfg.wpg, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pick_kernel<true>(sph_root != 0, s->deep, false), WAVE, 0) != hipSuccess || per_cu_t < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pick_kernel<true>(sph_root != 0, s->deep, false), WAVE * cfg.wpg, 0) != hipSuccess || per_cu_t < 1)
         per_cu_t = 4;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, pick_kernel<false>(sph_root != 0, s->deep, n_textri != 0, true), WAVE, 0) != hipSuccess || per_cu_l < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, pick_kernel<false>(sph_root != 0, s->deep, n_textri != 0, true), WAVE * cfg.wpg, 0) != hipSuccess || per_cu_l < 1)
         per_cu_l = 4;
     s->grid = pr.multiProcessorCount * per_cu;
     s->grid_trace = pr.multiProcessorCount * per_cu_t;
     s->grid_lights = pr.multiProcessorCount * per_cu_l;
-    const int n_slots = std::max(std::max(s->grid, s->grid_trace), s->grid_lights) * slot_stride(s->slots);
+    const int n_slots = std::max(std::max(s->grid, s->grid_trace), s->grid_lights) * s->wpg * slot_stride(s->slots);
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
     const int need_depth = tree_depth + 3 * cull_depth + 5 + (sph_root ? 1 : 0);
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK + 1 : 0; // levels that can move to HBM
@@ -2457,7 +2469,7 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
     const DevCamera dc = make_camera(cam);
     int grid_cap = 0;
     const KernelFn kern = render_kernel(s, p, &grid_cap);
-    const int grid = (int)std::min<long long>(grid_cap, (blocks * 256 + s->slots - 1) / s->slots);
+    const int grid = (int)std::min<long long>(grid_cap, (blocks * 256 + s->slots * s->wpg - 1) / (s->slots * s->wpg));
     HIP_TRY(hipEventRecord(s->ev0, stream));
     ColdArgs ca = s->cold;
     ca.cam = dc; ca.P = *p;
@@ -2466,7 +2478,7 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
     ca.n_work = (unsigned)(blocks * 256); ca.n_tiles = n_tiles;
     hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, stream, ca, (ColdArgs *)(scr + NA_OFF_COLD));
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, s->d, (const ColdArgs *)(scr + NA_OFF_COLD), s->d_stats);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, stream, s->d, (const ColdArgs *)(scr + NA_OFF_COLD), s->d_stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     s->timed = true;
@@ -2577,7 +2589,7 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_counter, 0, 16);
     if (e == hipSuccess) {
-        const long long want = (n + s->slots - 1) / s->slots;
+        const long long want = (n + s->slots * s->wpg - 1) / (s->slots * s->wpg);
         const int grid = (int)std::min<long long>(s->grid_trace, want); // stay within the slot count the state arrays were sized for
         const KernelFn kern = pick_kernel<true>(s->d.sph_root != 0, s->deep, false);
         ColdArgs ca = s->cold;
@@ -2585,7 +2597,7 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
         ca.counter = s->d_counter; ca.n_work = (unsigned)n;
         ca.rays = d_rays; ca.tri_id = d_ti; ca.tri_t = d_tt; ca.sph_id = d_si; ca.sph_t = d_st;
         hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, nullptr, ca, s->d_cold);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, nullptr, s->d, (const ColdArgs *)s->d_cold, s->d_stats);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, nullptr, s->d, (const ColdArgs *)s->d_cold, s->d_stats);
         e = hipGetLastError();
         s->last_stream = nullptr;
     }
