@@ -7,7 +7,9 @@
 //   KdTree::check / check_node, made iterative with a per-lane stack   kdtree.cpp:98-142
 //   KdTreeNode::check_aabb   kdtree.h:57-76
 //   Polygon::intersect       polygon.h:37-60
+//   Polygon::getcol with GetImageData (textured triangles)   polygon.h:30-35, 73-89
 //   Sphere::intersect / sphere_intersect   sphere.h:13-21, sphere.cpp:3-14
+// and, with no counterpart in the reference, explicit light sampling (rt_params.light_mode 1).
 //
 // Numerics: all arithmetic that decides a result is FP64 in the reference's operation order; this
 // file must be compiled with -ffp-contract=off so no multiply-add is fused (the CPU path has no
@@ -22,8 +24,8 @@
 // id; touched only on the chosen hit), SphGeom 32 B (centre, radius), SphShade 64 B (lig, col,
 // type), and per ray slot a column of 8-byte words (direction, best hit, shading state).
 //
-// Execution: a persistent grid of one-wavefront workgroups.  Each wavefront owns 140 ray slots
-// (one sub-pixel's current path each); slots take sub-pixels from an atomic counter in 8x8-block
+// Execution: a persistent grid of one-wavefront workgroups.  Each wavefront owns 152 ray slots (140
+// in the build for deep trees, see KernelCfg; one sub-pixel's current path each); slots take sub-pixels from an atomic counter in 8x8-block
 // order, a pixel's four always in one wavefront, and the one that finishes last adds the four
 // shares in the reference's order.  See k_main for the scheduling.
 //
@@ -504,22 +506,22 @@ __device__ __forceinline__ unsigned after_granule(unsigned x) { return (x & 0x01
 // The whole path -- camera ray, KdTree::check without recursion, check_node, sphere scan, radiance()
 // as a loop -- is cut into steps of four kinds:
 //     node   enter a kd-tree node: check_aabb, choose near / far child          (kdtree.cpp:111-141)
-//     cull   two child boxes of a long own list's culling hierarchy; the first such step of a list
+//     cull   four child boxes of an own list's culling hierarchy; the first such step of a list
 //            also does the bookkeeping of "the node's near child has returned"   (kdtree.cpp:122-125)
 //     tri    one exact triangle test                                            (kdtree.cpp:101-107)
 //     shade  sphere scan, material, next ray / next path / next pixel           (raytrace.cpp:41-95,196-205)
-// A workgroup is ONE wavefront that owns SLOTS = 140 ray slots.  A slot is a complete path tracer
+// A wavefront owns SLOTS ray slots (152, or 140 in the build for deep trees).  A slot is a complete path tracer
 // state: its ray origin and inverse direction, its current item, flags and the top of its
 // traversal stack live in LDS, the rest (direction, best hit, shading state) in HBM, and NOTHING
-// about a ray is held in registers between steps.  Each iteration the wavefront votes for the kind
-// of step most of its slots wait for, the (up to 64) slots of that kind are handed to the
-// lanes in slot order, every such lane runs the step for its slot (state from LDS, record from the
+// about a ray is held in registers between steps.  Each iteration the wavefront picks the kind
+// of step most of its slots wait for, the (up to 64) topmost slots on that kind's stack are handed to the
+// lanes, every such lane runs the step for its slot (state from LDS, record from the
 // pool, both loads issued together) and writes back the few words that changed.  Because the 64
 // rays of a packet diverge completely after the first bounce, this keeps most lanes active per
 // executed instruction, and the step bodies are straight-line code without loop-carried registers.
 //
-// TRACE = false: slots pull pixels (8x8 blocks, one slot per pixel) from an atomic counter and
-// run each pixel's 4*samps paths in the reference's order.  TRACE = true: slots pull explicit rays
+// TRACE = false: slots pull sub-pixels (8x8 blocks of pixels, a pixel's four in one wavefront) from an atomic
+// counter and run each sub-pixel's samps paths in the reference's order.  TRACE = true: slots pull explicit rays
 // and report the nearest triangle / sphere (raytrace.cpp:46-47).
 // a float kept in 16 bits: sign, exponent and the top 7 mantissa bits, the magnitude rounded up
 __device__ __forceinline__ unsigned short half_up_put(float x) { return (unsigned short)((__float_as_uint(x) + 0xFFFFu) >> 16); }
@@ -530,7 +532,7 @@ __device__ __forceinline__ float exp_up_get(unsigned char e) { return __uint_as_
 __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30f), 1e30f); }
 
 // SPH = true: the scene has a sphere hierarchy (a second instance, so that scenes without one do not pay for it).
-// SLOTS, LDS_STACK: see KernelCfg.
+// SLOTS, LDS_STACK, WPG: see KernelCfg.
 // FEAT selects what the shade step can do beyond the reference's untextured integrator (instances of their own, like
 // SPH): 1 = textured triangles, 2 = those and explicit light sampling (rt_params.light_mode 1).
 template <bool TRACE, bool SPH, int FEAT, int SLOTS, int LDS_STACK, int WPG>
