@@ -219,7 +219,7 @@ def main():
                                                     "140, 8, 1" if deep else "152, 4, 1")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from hardware counters cannot be collected inside this process; the figure of the
-        # last profiled full-size launch of the same workload is kept in bench_traffic.json (how: its "source")
+        # last profiled full-size launch of the same workload is kept in bench_counters.json (how: its "source")
         # (likewise the vector-instruction counters that show what binds the kernel)
         traffic, traffic_source, valu = None, None, None
         tf = os.path.join(ROOT, "bench_counters.json")

@@ -23,25 +23,26 @@ def _read_bmp(path):
     return a[::-1]  # stored bottom-up
 
 
-@pytest.mark.parametrize("which", ["cornell", "textured"])
+@pytest.mark.parametrize("which", ["cornell", "textured", "lamps"])
 def test_executable_output_matches_oracle(po, tmp_path, which):
     sys.path.insert(0, ROOT)
     from raytrace_amd import scenes
     exe = os.path.join(ROOT, "raytrace_amd", "bin", "raytrace_hip")
     assert os.path.exists(exe), f"{exe} is missing: run make -C raytrace_amd/csrc"
     sizex, sizey = 96, 128
-    sc = scenes.cornell_demo(sizex, sizey) if which == "cornell" else scenes.textured_room(sizex, sizey)
+    sc = {"cornell": scenes.cornell_demo, "textured": scenes.textured_room, "lamps": scenes.lamp_room}[which](sizex, sizey)
+    lights = 1 if which == "lamps" else 0  # --lights 1: explicit light sampling (no counterpart in the reference)
     for m in sc["meshes"]:
         m.pop("tri_cols", None)  # not representable in the scene file
     scene_file = scenes.write_scene_files(sc, str(tmp_path), c_samps=1, g_samps=2)
     out = str(tmp_path / "o.bmp")
-    r = subprocess.run([exe, scene_file, "-o", out, "--depth", "4", "--rr", "0", "--seed", "5", "--tile", "40"], capture_output=True, text=True, timeout=100)
+    r = subprocess.run([exe, scene_file, "-o", out, "--depth", "4", "--rr", "0", "--seed", "5", "--tile", "40", "--lights", str(lights)], capture_output=True, text=True, timeout=100)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert f"{scenes.num_tris(sc)} triangles, {len(sc['spheres'])} spheres" in r.stdout
     img = _read_bmp(out)
     assert img.shape == (sizex, sizey, 3)
     orc = po.OracleScene(sc)
-    kw = dict(samps=2, rr_depth=4, rr_mode=0, split_depth=2, hard_depth=100000, jitter=1, seed=5)  # g_samps of the scene file, the flags above
+    kw = dict(samps=2, rr_depth=4, rr_mode=0, split_depth=2, hard_depth=100000, jitter=1, seed=5, light_mode=lights)  # g_samps of the scene file, the flags above
     orgb, _, ost = orc.render_tile(po.make_camera(sc["camera"]["o"], sc["camera"]["d"], sizex, sizey), po.make_params(**kw), 0, 0, sizex, sizey, nthreads=8)
     want = po.draw_pixels(orgb)
     close = (np.abs(img.astype(np.int32) - want.astype(np.int32)).max(axis=-1) <= 1).mean()

@@ -101,6 +101,21 @@ def test_modes_alternate_on_one_scene_and_tiles_do_not_matter(ra, po):
             r, _, _ = dev.render_tile(cam, prm, x0, y0, min(24, 40 - x0), 16)
             parts[x0:x0 + r.shape[0], y0:y0 + 16] = r
     assert np.array_equal(parts, first)
+    # the device-buffer entry points (the allocating one and the one that allocates nothing) run the same instance
+    import torch
+    from raytrace_amd import frame
+    tiles = frame.plan_tiles(40, 48, 24, 16)
+    outs = []
+    for fn in (dev.render_tiles_device, dev.render_tiles_noalloc):
+        buf = torch.full((frame.tile_pixels(tiles), 3), -1.0, dtype=torch.float64, device="cuda:0")
+        fn(cam, prm, tiles, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(buf.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    k = 0
+    for (x0, y0, rows, cols) in tiles:
+        assert np.array_equal(outs[0][k:k + rows * cols].reshape(rows, cols, 3), first[x0:x0 + rows, y0:y0 + cols])
+        k += rows * cols
     bad = ra.capi.make_params(light_mode=2, **kw)
     with pytest.raises(Exception):
         dev.render_tile(cam, bad, 0, 0, 8, 8)
