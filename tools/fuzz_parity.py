@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wider parity sweep than the test suite: several generated scenes and seeds, explicit rays and a
-small frame each, HIP path against the CPU oracle (ids, distances and work counters bit-exact,
+two small frames each (the reference's integrator and explicit light sampling), HIP path against the CPU oracle (ids, distances and work counters bit-exact,
 pixels within 1e-9).  Run on the GPU box: python3 tools/fuzz_parity.py [n_rays]; set
 RT_HIP_DEEP_TREE=0 to exercise the kernel build for deep trees.  Prints one line per case, then OK."""
 import os
@@ -27,6 +27,10 @@ def main():
         cases.append((f"bunny{seed}", scenes.bunny_class(3000 + 4000 * (seed - 10), seed=seed), np.array([50, 40, 80.0]), 60.0))
         cases.append((f"sponza{seed}", scenes.sponza_class(15000 + 10000 * (seed - 10), seed=seed, detail=0.3), np.array([50, 40, 130.0]), 70.0))
     cases.append(("spheres", scenes.random_spheres(300, seed=5), np.array([50, 40, 80.0]), 80.0))
+    cases.append(("spheres3k", scenes.random_spheres(3000, seed=6), np.array([50, 50, 0.0]), 150.0))
+    cases.append(("lamps", scenes.lamp_room(), np.array([50, 40, 80.0]), 60.0))
+    cases.append(("texroom", scenes.textured_room(), np.array([20, 40, 40.0]), 60.0))
+    cases.append(("deep", scenes.deep_tree(), np.array([300, 300, 300.0]), 500.0))
     for name, sc, ctr, spr in cases:
         hs = ra.HostScene(sc)
         dev = ra.DeviceScene(hs, 0)
@@ -45,7 +49,14 @@ def main():
         assert np.array_equal(ids, oids), name
         assert np.abs(rgb - orgb).max() <= 1e-9, (name, np.abs(rgb - orgb).max())
         assert st["rays"] == ost["rays"] and st["node_visits"] == ost["node_visits"], (name, st, ost)
-        print(name, hs.num_tris, "tris:", n, "rays and a", sizex, "x", sizey, "frame agree;", a[4]["node_visits"], "visits", flush=True)
+        # the same frame with explicit light sampling (the oracle's restatement of the same estimator)
+        kw1 = dict(kw, light_mode=1, rr_mode=1, seed=4)
+        rgb, ids, st = dev.render_tile(ra.capi.make_camera(cam_o, cam_d, sizex, sizey), ra.capi.make_params(**kw1), 0, 0, sizex, sizey)
+        orgb, oids, ost = orc.render_tile(po.make_camera(cam_o, cam_d, sizex, sizey), po.make_params(**kw1), 0, 0, sizex, sizey, nthreads=16)
+        assert np.array_equal(ids, oids), name
+        assert np.abs(rgb - orgb).max() <= 1e-9, (name, np.abs(rgb - orgb).max())
+        assert st["rays"] == ost["rays"] and st["node_visits"] == ost["node_visits"] and st["tri_tests"] == ost["tri_tests"], (name, st, ost)
+        print(name, hs.num_tris, "tris:", n, "rays and two", sizex, "x", sizey, "frames agree;", a[4]["node_visits"], "visits", flush=True)
         dev.close()
     print("OK")
 
