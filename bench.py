@@ -126,6 +126,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the result: whatever libraries print there (RCCL's version banner at the
+    # first collective, for one) goes to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import raytrace_amd as ra
@@ -262,7 +268,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, (scene["camera"]["o"], scene["camera"]["d"]), sizex, sizey, pkw, args.cpu_budget)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
     if have_pg:
