@@ -755,20 +755,23 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 if (!pass) want_pop = true;
                 else {
                     l_tris += info >> 3; // the own list will be scanned (kdtree.cpp:122,131,137)
-                    const bool hasL = (info >> 2) & 1, hasR = right != 0;
-                    const bool lt = sw < split, gt = sw > split;
+                    // Truth values from here on are lane masks (one bit per lane, in scalar registers): combining them costs
+                    // no vector instruction, and a select takes the mask as it is.
+                    typedef unsigned long long LaneMask;
+                    auto lanes = [](LaneMask m) __attribute__((always_inline)) { return __builtin_amdgcn_inverse_ballot_w64(m); };
+                    const LaneMask mHasL = __ballot(((info >> 2) & 1u) != 0), mHasR = __ballot(right != 0);
+                    const LaneMask mLt = __ballot(sw < split), mGt = __ballot(sw > split), mVpos = __ballot(vpos), mVneg = __ballot(vneg);
                     // kdtree.cpp:119-127 (left of the plane), 128-136 (right of it), 137-141 (on it: only
                     // the child the ray points into)
-                    const bool nearL = hasL & (lt | (!gt & vneg)), nearR = hasR & !nearL & (gt | (!lt & vpos));
-                    unsigned near = nearL ? node + 4 : nearR ? right : 0u;
-                    unsigned farkind = (lt & hasR & vpos) ? 2u : (gt & hasL & vneg) ? 1u : 0u; // 1: left child, 2: right child
+                    const LaneMask mNearL = mHasL & (mLt | (~mGt & mVneg)), mNearR = mHasR & ~mNearL & (mGt | (~mLt & mVpos));
+                    const LaneMask mFarR = mLt & mHasR & mVpos, mFarL = mGt & mHasL & mVneg; // the far child, if the near subtree returns false
                     // A child whose check_aabb is certain to fail is not visited, only counted: check_aabb
                     // accepts nothing that misses the child's box grown by `pad` (see above), and the
                     // quantised boxes contain the exact ones, so the single-precision slab test of the
                     // culling records (same expression, same error bound, inflation `pad`) decides it.
                     // The own list's box (inflated like the boxes of its hierarchy) is tested the same way: a
                     // list the ray cannot meet, or an empty one, needs no step of its own.
-                    bool list_missed;
+                    LaneMask mMet[3], mNokids, mEmpty, mHasList;
                     {
                         typedef float f2 __attribute__((ext_vector_type(2)));
                         const float sf[3] = {(float)s[0], (float)s[1], (float)s[2]};
@@ -789,7 +792,6 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                             ka[i] = (f2){a1, a1};
                             kb[i] = (f2){(kbase[i] - (sf[i] + mt)) * ivf[i], (kbase[i] - (sf[i] - mt)) * ivf[i]};
                         }
-                        bool met[3];
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
                             float ta[3], tb[3];
@@ -803,20 +805,25 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                                 tb[i] = fmaxf(t.x, t.y);
                             }
                             const float tmin = fmaxf(fmaxf(ta[0], ta[1]), fmaxf(ta[2], 0.0f)), tmax = fminf(fminf(tb[0], tb[1]), tb[2]);
-                            met[k] = tmin * 0.999999f <= tmax;
+                            mMet[k] = __ballot(tmin * 0.999999f <= tmax);
                         }
-                        if (kflags & KID_NOKIDS) met[0] = met[1] = true; // boxes marked unusable cull nothing
-                        list_missed = (kflags & KID_EMPTY) != 0 || ((kflags & KID_LIST) != 0 && !met[2]);
-                        if (near != 0 && !met[nearL ? 0 : 1]) { near = 0; skipped = true; } // its check() returns false at once
-                        if (farkind != 0 && !met[farkind == 1 ? 0 : 1]) farkind = 3;          // likewise, if it comes to that
+                        mNokids = __ballot((kflags & KID_NOKIDS) != 0); // boxes marked unusable cull nothing
+                        mEmpty = __ballot((kflags & KID_EMPTY) != 0);
+                        mHasList = __ballot((kflags & KID_LIST) != 0);
                     }
+                    const LaneMask mMetL = mMet[0] | mNokids, mMetR = mMet[1] | mNokids;
+                    const LaneMask mListMissed = mEmpty | (mHasList & ~mMet[2]);
+                    const LaneMask mHasNear = (mNearL & mMetL) | (mNearR & mMetR); // a near child that cannot pass its box: check() returns false at once
+                    const LaneMask mFar0 = mFarL | mFarR, mFar12 = (mFarL & mMetL) | (mFarR & mMetR), mFar3 = mFar0 & ~mFar12; // far3: likewise, if it comes to that
+                    const unsigned left = node + 4;
+                    const unsigned near = lanes(mNearL) ? left : right, far_item = lanes(mFarL) ? left : right;
                     // the own list and the far child come after the near subtree; the frame's flag
                     // travels in the item and the near subtree starts with a clean one
-                    const unsigned st0 = st;
-                    const unsigned pend = (st >> ST_NSH) & 7u; // counted-only far children of the frame so far
-                    const unsigned after = IT_AFTER | (((st >> 8) & 1u) << 30) | (farkind << 28) | (pend << IT_NSH) | (node >> 1);
-                    const unsigned far_item = farkind == 1 ? node + 4 : right;
-                    // (written as selects: three cases)
+                    // (far child in the item: 1 left, 2 right, 3 only counted; the frame's flag; its count-only children so far)
+                    const unsigned common = IT_AFTER | ((st & ST_FLAG) << 22) | (lanes(mFarL | mFar3) ? 1u << 28 : 0u) | (lanes(mFarR | mFar3) ? 1u << 29 : 0u) |
+                                            ((st & ST_N) << (IT_NSH - ST_NSH));
+                    const unsigned after = common | (node >> 1);
+                    // (three cases)
                     //  * the list has to be scanned: after item under the near subtree, or next if there is none;
                     //  * nothing to scan after the near subtree: a marker (an after item with bit 0 set, which the
                     //    tail of whatever step pops it handles) restores the flag and decides about the far child,
@@ -824,18 +831,19 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     //    (no far child, clear flag to restore);
                     //  * no near subtree either: check() goes straight to the far child (kdtree.cpp:124,133), and a
                     //    far child that fails at its box is only counted.
-                    const bool has_near = near != 0, far12 = farkind == 1 || farkind == 2;
-                    const unsigned marker = IT_AFTER | (((st0 >> 8) & 1u) << 30) | (farkind << 28) | (pend << IT_NSH) | (far12 ? far_item >> 1 : 0u) | 1u;
+                    const unsigned marker = common | (lanes(mFar12) ? far_item >> 1 : 0u) | 1u;
+                    const LaneMask mFlag = __ballot((st & ST_FLAG) != 0), mRoom = __ballot(((st >> ST_NSH) & 7u) < N_MAX);
                     // (a far child that is only counted joins the frame's number instead, while that has room)
-                    const bool count_only = farkind == 3 && (st0 & ST_FLAG) == 0 && pend < N_MAX;
-                    const bool want_marker = (farkind != 0 || (st0 & ST_FLAG) != 0) && !count_only;
-                    if (!list_missed || has_near) st &= ~ST_FLAG;
-                    if (has_near && list_missed && count_only) st += 1u << ST_NSH;
-                    if (!list_missed || (has_near && want_marker)) st &= ~ST_N; // the item starts a frame of its own
-                    push_item = !has_near ? 0u : !list_missed ? after : want_marker ? marker : 0u;
-                    next = has_near ? near : !list_missed ? after : far12 ? far_item : 0u;
-                    skipped_far = list_missed && !has_near && farkind == 3;
-                    want_pop = list_missed && !has_near && !far12;
+                    const LaneMask mCountOnly = mFar3 & ~mFlag & mRoom;
+                    const LaneMask mWantMarker = (mFar0 | mFlag) & ~mCountOnly;
+                    st = lanes(~mListMissed | mHasNear) ? st & ~ST_FLAG : st;
+                    st = lanes(mHasNear & mListMissed & mCountOnly) ? st + (1u << ST_NSH) : st;
+                    st = lanes(~mListMissed | (mHasNear & mWantMarker)) ? st & ~ST_N : st; // the item starts a frame of its own
+                    push_item = lanes(mHasNear & ~mListMissed) ? after : lanes(mHasNear & mWantMarker) ? marker : 0u;
+                    next = lanes(mHasNear) ? near : lanes(~mListMissed) ? after : lanes(mFar12) ? far_item : 0u;
+                    skipped = lanes((mNearL | mNearR) & ~mHasNear);
+                    skipped_far = lanes(mListMissed & ~mHasNear & mFar3);
+                    want_pop = lanes(mListMissed & ~mHasNear & ~mFar12);
                 }
             }
             if (refill) { // levels [slo', sp - 1) go to the ring, level sp - 1 continues
