@@ -846,6 +846,10 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     want_pop = lanes(mListMissed & ~mHasNear & ~mFar12);
                 }
             }
+#ifndef RT_NO_CONSUME
+            if (REFILL == 3) asm volatile("" : : "v"(rf[0]), "v"(rf[1]), "v"(rf[2])); // (delivery taken on every path, see the cull step)
+            if (REFILL == 4) asm volatile("" : : "v"(rf[0]), "v"(rf[1]), "v"(rf[2]), "v"(rf[REFILL - 1]));
+#endif
             if (refill) { // levels [slo', sp - 1) go to the ring, level sp - 1 continues
                 sp--;
                 next = rf[0];
@@ -873,6 +877,13 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 float mg = exp_up_get(sM[sl]);
                 // (for an after item the flag of the enclosing frame is restored below: st or the item's bit)
                 // (the sphere hierarchy keeps only the nearest sphere: its boxes are always limited by that distance)
+#ifndef RT_NO_CONSUME
+                // Every lane takes delivery of all it loaded, here: a load whose result some path never reads counts as in
+                // flight for the compiler from then on, and it then puts full waits -- which also wait for the stores
+                // issued since -- in front of whatever next writes those registers, in this step's tail and in the next step.
+                asm volatile("" : : "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w), "v"(r2.x), "v"(r2.y),
+                             "v"(r2.z), "v"(r2.w), "v"(it.x), "v"(it.y), "v"(it.z), "v"(it.w), "v"(hdr.x), "v"(hdr.y));
+#endif
                 const bool sph_boxes = SPH && !(cur & IT_AFTER) && (cur & IDX28) >= S.g_sphc;
                 const bool lim_on = sph_boxes || ((st & ST_FLAG) != 0) || ((cur & IT_AFTER) && ((cur >> 30) & 1));
                 float best_lim = half_up_get(sT[sl]);
@@ -997,6 +1008,10 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 const d3 d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
                 const double best_t = ls[LS_BT * lss];
                 const double2 a = sA[sl], b = sB[sl];
+#ifndef RT_NO_CONSUME
+                asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q1.x), "v"(q1.y), "v"(q2.x), "v"(q2.y), "v"(q3.x), "v"(q3.y), "v"(q4.x), "v"(q4.y),
+                             "v"(d.x), "v"(d.y), "v"(d.z), "v"(best_t)); // (delivery taken on every path, see the cull step)
+#endif
                 const d3 o = mk(a.x, a.y, b.x);
                 is_sph = SPH && (cur & IDX28) >= S.g_sph;
                 if (is_sph) { // ---- one sphere of the sphere hierarchy (sphere.h:13-21, sphere.cpp:7)
