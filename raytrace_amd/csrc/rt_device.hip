@@ -1417,11 +1417,16 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         {
             const unsigned nk = (!run || done) ? (unsigned)K_DONE : next == IT_END ? (unsigned)K_SHADE : is_marker(next) ? (unsigned)K_NODE : (next & IT_AFTER) ? (unsigned)K_CULL : (next >> 29) & 3u;
             const unsigned long long m0 = __ballot(nk == K_NODE), m1 = __ballot(nk == K_CULL), m2 = __ballot(nk == K_TRI), m3 = __ballot(nk == K_SHADE);
-            const unsigned long long mine = nk == K_NODE ? m0 : nk == K_CULL ? m1 : nk == K_TRI ? m2 : m3;
-            const int below = nk == K_NODE ? q0 : nk == K_CULL ? q1 : nk == K_TRI ? q2 : q3;
-            const int at = below + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
+            // (the place on each of the four stacks, then one of them: the masks and counts are scalars, and picking among
+            // scalars per lane costs a move and a select each -- more than counting four times)
+            auto rank = [](unsigned long long m) __attribute__((always_inline)) {
+                return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            };
+            const int i0 = 2 * wslot0 + q0 + rank(m0), i1 = 2 * wslot0 + SLOTS - 1 - q1 - rank(m1);
+            const int i2 = 2 * wslot0 + SLOTS + q2 + rank(m2), i3 = 2 * wslot0 + 2 * SLOTS - 1 - q3 - rank(m3);
+            const int qi = nk == K_NODE ? i0 : nk == K_CULL ? i1 : nk == K_TRI ? i2 : i3;
             if (nk != K_DONE)
-                sQ[qindex((int)nk, at)] = make_uint2((unsigned)slot | (((st & (ST_FLAG | ST_N | ST_FAR)) | (unsigned)sp | ((unsigned)slo << ST_LO)) << 8), next == IT_END ? 0u : next);
+                sQ[qi] = make_uint2((unsigned)slot | (((st & (ST_FLAG | ST_N | ST_FAR)) | (unsigned)sp | ((unsigned)slo << ST_LO)) << 8), next == IT_END ? 0u : next);
             q0 += __popcll(m0); q1 += __popcll(m1); q2 += __popcll(m2); q3 += __popcll(m3);
         }
 #ifdef RT_PROFILE
