@@ -875,6 +875,8 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 const uint2 hdr = *(const uint2 *)(S.lhdr + ((cur & IT_AFTER) ? after_granule(cur) >> 2 : 0u));
                 const double2 a = sA[sl], b = sB[sl], c = sC[sl];
                 float mg = exp_up_get(sM[sl]);
+                const float gfac = exp_up_get(sG[sl]); // (read with the rest: only a list's first step uses it, but a read of its own there is a round trip of its own)
+                float best_lim = half_up_get(sT[sl]);
                 // (for an after item the flag of the enclosing frame is restored below: st or the item's bit)
                 // (the sphere hierarchy keeps only the nearest sphere: its boxes are always limited by that distance)
 #ifndef RT_NO_CONSUME
@@ -886,7 +888,6 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
 #endif
                 const bool sph_boxes = SPH && !(cur & IT_AFTER) && (cur & IDX28) >= S.g_sphc;
                 const bool lim_on = sph_boxes || ((st & ST_FLAG) != 0) || ((cur & IT_AFTER) && ((cur >> 30) & 1));
-                float best_lim = half_up_get(sT[sl]);
                 if (sph_boxes) best_lim = (float)ls[LS_ST * lss];
                 boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
@@ -897,14 +898,12 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     vis_add += near_hit ? 0u : ((st >> ST_NSH) & 7u) + (farkind == 3 ? 1u : 0u);
                     st = (st & ~ST_N) | (((cur >> IT_NSH) & 7u) << ST_NSH);
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
-                    if (farkind == 3) {}
-                    else if (farkind != 0 && !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list
+                    if (((farkind - 1u) < 2u) & !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list (one condition, one branch)
                     if (meta & LIST_SHORT) { // up to SMALL_LIST triangles: a chain of tri steps in list order
                         boxes = false;
                         if ((meta & 0xFF) == 0) want_pop = true;
                         else next = it.x;
                     } else { // inflation of this list's boxes, see ray_margin_factor(); a larger one only culls less
-                        const float gfac = exp_up_get(sG[sl]);
                         // (the exponent in the low mantissa bits only makes the coefficient a little larger)
                         mg = ldexpf(__uint_as_float(meta), (st & ST_FAR) ? (int)(meta & 0xFFu) : 0) * gfac;
                         { const unsigned char h = exp_up_put(mg); sM[sl] = h; mg = exp_up_get(h); }
