@@ -745,7 +745,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 bool pass = inside | clear;
                 bool vpos = iw > 0, vneg = iw < 0; // sign of the direction along the split axis
                 ev_exact = (maybe & !pass) | (fabs(iw) >= 1e299);
-                if ((maybe & !pass) | (fabs(iw) >= 1e299)) { // rare: needs the direction itself
+                if (__builtin_expect((maybe & !pass) | (fabs(iw) >= 1e299), 0)) { // rare: needs the direction itself
                     const double v[3] = {ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]};
                     if (!pass) pass = maybe && aabb_hit(mi, ma, s, v);
                     const double vw = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
