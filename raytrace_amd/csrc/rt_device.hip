@@ -691,7 +691,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
             RT_MARK("node");
             const bool refill = run && cur == IT_REFILL;
             const bool marker = run && is_marker(cur); // a second marker in a row (see the tail)
-            if (marker) want_pop = do_marker(cur);
+            if (__builtin_expect(marker, 0)) want_pop = do_marker(cur);
             unsigned rf[REFILL];
             if (refill) { // issue the loads of levels sp - 1 (the item to continue with), sp - 2, ...
 #pragma unroll
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     st = (st & ~ST_N) | (((cur >> IT_NSH) & 7u) << ST_NSH);
                     if ((cur >> 30) & 1) st |= ST_FLAG;                 // back in the enclosing frame
                     if (((farkind - 1u) < 2u) & !near_hit) push(farkind == 1 ? node + 4 : right); // kdtree.cpp:124,133: after the list (one condition, one branch)
-                    if (meta & LIST_SHORT) { // up to SMALL_LIST triangles: a chain of tri steps in list order
+                    if (__builtin_expect((meta & LIST_SHORT) != 0, 0)) { // up to SMALL_LIST triangles: a chain of tri steps in list order
                         boxes = false;
                         if ((meta & 0xFF) == 0) want_pop = true;
                         else next = it.x;
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                         if (LDS_STACK >= 4 || sp - slo + 3 <= LDS_STACK) {
                             if (LDS_STACK >= 4) { // make room first: the oldest levels move to HBM
                                 const int over = sp - slo + (n4 - 1) - LDS_STACK;
-                                if (over > 0) {
+                                if (__builtin_expect(over > 0, 0)) {
 #pragma unroll
                                     for (int k = 0; k < 3; k++)
                                         if (k < over) S.ovf[(unsigned)(slo + k) * (unsigned)S.n_slots + gslot0 + (unsigned)slot] = stk[(slo + k) & (LDS_STACK - 1)][sl];
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     // strict < keeps the earlier of two equal distances; inside one list "earlier"
                     // is the lower rank, across lists it is the list visited first
                     bool better = t < best_t;
-                    if (t == best_t && t < 1e20) { // rare: the two triangles' lists and ranks decide
+                    if (__builtin_expect(t == best_t && t < 1e20, 0)) { // rare: the two triangles' lists and ranks decide
                         const uint2 lb = S.tlist[((const unsigned *)&ls[LS_HA * lss])[0]], lc = S.tlist[(unsigned)w9 & ~TRI_LAST];
                         better = lb.x == lc.x && rk < (int)lb.y;
                     }
