@@ -878,17 +878,21 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 const float gfac = exp_up_get(sG[sl]); // (read with the rest: only a list's first step uses it, but a read of its own there is a round trip of its own)
                 float best_lim = half_up_get(sT[sl]);
                 // (for an after item the flag of the enclosing frame is restored below: st or the item's bit)
-                // (the sphere hierarchy keeps only the nearest sphere: its boxes are always limited by that distance)
+                // (the sphere hierarchy keeps only the nearest sphere: its boxes are always limited by that distance,
+                // a word of the slot's state in HBM that is fetched with the record)
+                const bool sph_boxes = SPH && !(cur & IT_AFTER) && (cur & IDX28) >= S.g_sphc;
+                double sph_best = 0;
+                if (SPH && sph_boxes) sph_best = ls[LS_ST * lss];
 #ifndef RT_NO_CONSUME
                 // Every lane takes delivery of all it loaded, here: a load whose result some path never reads counts as in
                 // flight for the compiler from then on, and it then puts full waits -- which also wait for the stores
                 // issued since -- in front of whatever next writes those registers, in this step's tail and in the next step.
                 asm volatile("" : : "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w), "v"(r2.x), "v"(r2.y),
                              "v"(r2.z), "v"(r2.w), "v"(it.x), "v"(it.y), "v"(it.z), "v"(it.w), "v"(hdr.x), "v"(hdr.y));
+                if (SPH) asm volatile("" : : "v"(sph_best));
 #endif
-                const bool sph_boxes = SPH && !(cur & IT_AFTER) && (cur & IDX28) >= S.g_sphc;
                 const bool lim_on = sph_boxes || ((st & ST_FLAG) != 0) || ((cur & IT_AFTER) && ((cur >> 30) & 1));
-                if (sph_boxes) best_lim = (float)ls[LS_ST * lss];
+                if (sph_boxes) best_lim = (float)sph_best;
                 boxes = true;
                 if (cur & IT_AFTER) { // near child finished: own list (kdtree.cpp:122,131,137), then far child
                     const unsigned right = hdr.x, meta = hdr.y;
@@ -1007,12 +1011,15 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 const d3 d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
                 const double best_t = ls[LS_BT * lss];
                 const double2 a = sA[sl], b = sB[sl];
+                is_sph = SPH && (cur & IDX28) >= S.g_sph;
+                double sph_ts = 0; // the nearest sphere so far, fetched with the record
+                if (SPH && is_sph) sph_ts = ls[LS_ST * lss];
 #ifndef RT_NO_CONSUME
+                if (SPH) asm volatile("" : : "v"(sph_ts));
                 asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q1.x), "v"(q1.y), "v"(q2.x), "v"(q2.y), "v"(q3.x), "v"(q3.y), "v"(q4.x), "v"(q4.y),
                              "v"(d.x), "v"(d.y), "v"(d.z), "v"(best_t)); // (delivery taken on every path, see the cull step)
 #endif
                 const d3 o = mk(a.x, a.y, b.x);
-                is_sph = SPH && (cur & IDX28) >= S.g_sph;
                 if (is_sph) { // ---- one sphere of the sphere hierarchy (sphere.h:13-21, sphere.cpp:7)
                     const int i = (int)(((cur & IDX28) - S.g_sph) >> 1);
                     const d3 op = mk(q0.x, q0.y, q1.x) - o; // the pool's copy of the sphere: centre, radius
@@ -1026,7 +1033,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                         t = bb - det;
                         if (!(t > EPS)) { t = bb + det; if (!(t > EPS)) t = 1e20; }
                     }
-                    const double ts = ls[LS_ST * lss];
+                    const double ts = sph_ts;
                     // the reference scans from the last sphere down with strict <: of equal distances the higher index wins
                     if (t < ts || (t == ts && t < 1e20 && i > (int)__double_as_longlong(ls[LS_SI * lss]))) {
                         ls[LS_ST * lss] = t;
