@@ -862,7 +862,8 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
             RT_EV(16, run && !refill && !marker && !ev_fail && next != 0 && !want_pop && push_item == 0); // goes on without a push
             const int entered = nrun - (int)__popcll(__ballot(refill | marker)); // lanes that fetched a node's records
             RT_SCOUNT(c_nfetch, entered);
-            RT_SCOUNT(c_visits, entered + (int)__popcll(__ballot(skipped)) + (int)__popcll(__ballot(skipped_far)));
+            RT_SCOUNT(c_visits, entered);
+            vis_add += (skipped ? 1u : 0u) + (skipped_far ? 1u : 0u); // (per lane: two wavefront-wide counts fewer)
         } else if (pick == K_CULL) {
             RT_MARK("cull");
             bool boxes = false;
