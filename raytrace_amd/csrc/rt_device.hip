@@ -585,24 +585,33 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
     // work counters: wavefront-uniform 32-bit sums of lane counts in scalar registers, flushed to
     // the 64-bit totals in HBM long before they can overflow; only the own-list lengths need a
     // per-lane sum
-    unsigned c_rays = 0, c_visits = 0, c_shades = 0, c_done = 0, c_culls = 0, c_iters = 0, c_lanes = 0;
-    unsigned c_nfetch = 0, c_sphdone = 0, c_scans = 0; // node records fetched; spheres tested one by one; rays that scanned all spheres
+    unsigned c_rays = 0, c_shades = 0, c_done = 0, c_iters = 0, c_lanes = 0;
+    unsigned c_sphdone = 0, c_scans = 0; // spheres tested one by one; rays that scanned all spheres
     unsigned long long l_tris = 0;
-    unsigned l_vis = 0; // visits counted by single lanes (far children that are only counted)
+    // counted per lane (an add under the lane's own condition is cheaper than a wavefront-wide count and an add to a counter
+    // that every path through the step has to carry): node visits, node records fetched, culling records tested
+    unsigned l_vis = 0, l_nf = 0, l_culls = 0;
+    auto flush_lanes = [&]() __attribute__((always_inline)) {
+        unsigned long long vis = l_vis, nf = l_nf, cu = l_culls;
+        for (int off = 32; off > 0; off >>= 1) { vis += __shfl_down(vis, off, 64); nf += __shfl_down(nf, off, 64); cu += __shfl_down(cu, off, 64); }
+        if (lane == 0) {
+            if (vis) atomicAdd(gstats + ST_VISITS, vis);
+            if (nf) atomicAdd(gstats + ST_NFETCH, nf);
+            if (cu) atomicAdd(gstats + ST_CULLS, cu);
+        }
+        l_vis = l_nf = l_culls = 0;
+    };
     auto flush = [&]() __attribute__((always_inline)) {
         if (lane == 0) {
             if (c_rays) { atomicAdd(gstats + ST_RAYS, (unsigned long long)c_rays); atomicAdd(gstats + ST_SPHS, (unsigned long long)c_rays * (unsigned)S.n_sph); }
-            if (c_visits) atomicAdd(gstats + ST_VISITS, (unsigned long long)c_visits);
             if (c_shades) atomicAdd(gstats + ST_SHADES, (unsigned long long)c_shades);
             if (c_done) atomicAdd(gstats + ST_DONE, (unsigned long long)c_done);
-            if (c_culls) atomicAdd(gstats + ST_CULLS, (unsigned long long)c_culls);
             atomicAdd(gstats + ST_ITERS, (unsigned long long)c_iters);
             atomicAdd(gstats + ST_LANES, (unsigned long long)c_lanes);
-            if (c_nfetch) atomicAdd(gstats + ST_NFETCH, (unsigned long long)c_nfetch);
             if (c_sphdone | c_scans) atomicAdd(gstats + ST_SPHDONE, (unsigned long long)c_sphdone + (unsigned long long)c_scans * (unsigned)S.n_sph);
         }
-        c_rays = c_visits = c_shades = c_done = c_culls = c_iters = c_lanes = 0;
-        c_nfetch = c_sphdone = c_scans = 0;
+        c_rays = c_shades = c_done = c_iters = c_lanes = 0;
+        c_sphdone = c_scans = 0;
     };
 #define RT_SCOUNT(c, n) (c) += (unsigned)(n)
 
@@ -860,10 +869,9 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
             }
             RT_EV(0, run && !refill && !marker); RT_EV(1, ev_exact); RT_EV(2, refill); RT_EV(3, marker); RT_EV(4, ev_fail);
             RT_EV(16, run && !refill && !marker && !ev_fail && next != 0 && !want_pop && push_item == 0); // goes on without a push
-            const int entered = nrun - (int)__popcll(__ballot(refill | marker)); // lanes that fetched a node's records
-            RT_SCOUNT(c_nfetch, entered);
-            RT_SCOUNT(c_visits, entered);
-            vis_add += (skipped ? 1u : 0u) + (skipped_far ? 1u : 0u); // (per lane: two wavefront-wide counts fewer)
+            const bool fetched = run && !refill && !marker; // lanes that fetched a node's records
+            l_nf += fetched ? 1u : 0u;
+            vis_add += (fetched ? 1u : 0u) + (skipped ? 1u : 0u) + (skipped_far ? 1u : 0u);
         } else if (pick == K_CULL) {
             RT_MARK("cull");
             bool boxes = false;
@@ -1001,7 +1009,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 }
             }
             RT_EV(5, run && (cur & IT_AFTER)); RT_EV(6, boxes); RT_EV(7, boxes && want_pop); RT_EV(8, run && !boxes);
-            RT_SCOUNT(c_culls, (unsigned)__popcll(__ballot(boxes)));
+            l_culls += boxes ? 1u : 0u;
         } else if (pick == K_TRI) {
             RT_MARK("tri");
             bool is_sph = false;
@@ -1389,7 +1397,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
             RT_SCOUNT(c_rays, (unsigned)__popcll(__ballot(ev_ray)));
             RT_SCOUNT(c_shades, (unsigned)__popcll(__ballot(ev_shade)));
             RT_SCOUNT(c_scans, (unsigned)__popcll(__ballot(ev_scan)));
-            if (c_iters >> 24) flush();
+            if (c_iters >> 24) { flush(); flush_lanes(); } // (long before a 32-bit counter can overflow)
         }
 
         // ---- common tail for the lanes that ran: push, pop, publish the slot's next item
@@ -1458,9 +1466,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
     flush();
     for (int off = 32; off > 0; off >>= 1) l_tris += __shfl_down(l_tris, off, 64);
     if (lane == 0 && l_tris) atomicAdd(gstats + ST_TRIS, l_tris);
-    unsigned long long vis = l_vis;
-    for (int off = 32; off > 0; off >>= 1) vis += __shfl_down(vis, off, 64);
-    if (lane == 0 && vis) atomicAdd(gstats + ST_VISITS, vis);
+    flush_lanes();
 #undef RT_SCOUNT
 }
 
