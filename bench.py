@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--sizey", type=int, default=0)
     ap.add_argument("--samps", type=int, default=1)
     ap.add_argument("--tile", type=int, default=64)
+    # frames in flight per rank (0: one on one GPU, where the kernel's own duration is what the roofline is made of;
+    # two on several, where a rank's share of the frame is short and its tail and the gather overlap the next frame)
+    ap.add_argument("--in-flight", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -162,7 +165,8 @@ def main():
     cam = ra.capi.make_camera(scene["camera"]["o"], scene["camera"]["d"], sizex, sizey)
     pkw = dict(samps=args.samps, rr_depth=mode["rr_depth"], rr_mode=mode["rr_mode"], split_depth=2, hard_depth=64, jitter=1, seed=1)
     prm = ra.capi.make_params(**pkw)
-    fr = frame.FrameRenderer(dev, cam, prm, args.tile, args.tile, rank=rank, world=world, device=device)
+    in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 2)
+    pipe = frame.FramePipeline(dev, cam, prm, in_flight, tile_rows=args.tile, tile_cols=args.tile, rank=rank, world=world, device=device)
     if world == 1 and pg_mode == "late":
         import tempfile
         store = os.path.join(tempfile.mkdtemp(prefix="rt_bench_pg_"), "store")
@@ -176,13 +180,7 @@ def main():
             torch.cuda.synchronize(device)
 
     def step(i, ev=None):
-        fr.params.seed = 1 + i  # a fresh random stream every frame
-        if ev is not None:
-            ev[0].record()
-        fr.launch()
-        if ev is not None:
-            ev[1].record()
-        fr.assemble()
+        pipe.submit(1 + i, ev)  # a fresh random stream every frame
 
     for i in range(args.warmup):
         step(i)
@@ -244,11 +242,13 @@ def main():
             "config": {"workload": scene["name"], "triangles": host.num_tris, "spheres": host.num_spheres, "sizex_rows": sizex,
                        "sizey_cols": sizey, "samps_per_subpixel": args.samps, "paths_per_pixel": 4 * args.samps,
                        "max_depth": mode["rr_depth"], "russian_roulette": bool(mode["rr_mode"]), "tile": args.tile,
-                       "parallelism": f"tiles%{world} + gather", "rays_per_frame": rays_total / args.steps},
+                       "parallelism": f"tiles%{world} + gather", "frames_in_flight": in_flight, "rays_per_frame": rays_total / args.steps},
             "frame_time_ms": elapsed / args.steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_measured_in_this_run": False if traffic is not None else None,
                          "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms_avg": avg_ms,
+                         # with two frames in flight a launch shares the chip with its neighbours for part of its run
+                         "kernels_overlap": in_flight > 1,
                          # what the counters say limits this kernel: vector-instruction issue, not bytes
                          "limiter": "valu_issue" if valu else None, "valu_issue": valu,
                          "per_ray": {"node_visits": per_launch["node_visits"] / max(1, per_launch["rays"]),

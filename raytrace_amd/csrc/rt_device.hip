@@ -1546,17 +1546,14 @@ int fail(int code, const char *fmt, ...) {
 
 } // namespace
 
-struct rt_scene {
-    int dev = 0;
-    DevScene d{};
-    ColdArgs cold{};            // the scene's part of the cold arguments (shading records, scene extent)
-    ColdArgs *d_cold = nullptr; // where a launch's cold arguments go
-    void *pool = nullptr, *tshade = nullptr, *tlist = nullptr, *sph = nullptr, *sshade = nullptr, *tex = nullptr;
-    void *ovf = nullptr, *lstate = nullptr, *lhdr = nullptr, *lights = nullptr;
-    int tree_depth = 0;
-    int grid = 0, grid_trace = 0, grid_lights = 0; // persistent workgroups of the render / explicit-ray / light-sampling kernel
+// What ONE launch in flight owns beyond the scene: the per-slot state of its rays, its work counter, its cold arguments,
+// its tile tables and the sub-pixels' shares.  A scene has two of these, so that two launches on two streams may overlap
+// (one frame's last paths with the next frame's first: short frames gain most); the second is allocated when a second
+// stream first shows up.
+struct LaunchCtx {
+    void *ovf = nullptr, *lstate = nullptr;
+    ColdArgs *d_cold = nullptr; // where the launch's cold arguments go
     unsigned *d_counter = nullptr; // [0] block counter
-    unsigned long long *d_stats = nullptr;
     int *d_blk_tile = nullptr; // tile of every 8x8 block of the current tile list
     long long blk_cap = 0;
     DevTile *d_tiles = nullptr;
@@ -1566,15 +1563,34 @@ struct rt_scene {
     double *d_sub = nullptr;     // shares of the sub-pixels of the frame being rendered [pixel][4][3]
     unsigned *d_subcnt = nullptr; // finished sub-pixels per pixel
     size_t sub_cap = 0;          // pixels both hold
+    hipEvent_t ev_tables = nullptr;       // recorded behind the last upload of the tile tables
+    hipStream_t tables_stream = nullptr;  // the stream that upload was queued on
+    bool tables_valid = false;            // d_tiles / d_blk_tile hold what h_tiles / h_blk_tile say
+    bool tables_stream_set = false;       // an upload has been queued at all
+    hipEvent_t ev_done = nullptr;         // recorded behind the last launch that used this set
+    hipStream_t stream = nullptr;         // the stream of that launch
+    bool allocated = false, used = false;
+    unsigned long long seq = 0;           // when it was last used
+};
+constexpr int N_CTX = 2;
+
+struct rt_scene {
+    int dev = 0;
+    DevScene d{};               // (its ovf / lstate are set per launch, from the launch's LaunchCtx)
+    ColdArgs cold{};            // the scene's part of the cold arguments (shading records, scene extent)
+    void *pool = nullptr, *tshade = nullptr, *tlist = nullptr, *sph = nullptr, *sshade = nullptr, *tex = nullptr;
+    void *lhdr = nullptr, *lights = nullptr;
+    LaunchCtx ctx[N_CTX];
+    unsigned long long launches = 0;
+    int ovf_depth = 0, n_slots = 0; // what sizes a LaunchCtx's per-slot arrays
+    int tree_depth = 0;
+    int grid = 0, grid_trace = 0, grid_lights = 0; // persistent workgroups of the render / explicit-ray / light-sampling kernel
+    unsigned long long *d_stats = nullptr;
     double *d_stage_rgb = nullptr; // rt_render_tile's device-side output buffers, kept between calls
     int *d_stage_prim = nullptr;
     size_t stage_cap = 0;        // pixels both hold
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t ev_tables = nullptr;       // recorded behind the last upload of the tile tables
-    hipStream_t tables_stream = nullptr;  // the stream that upload was queued on
-    bool tables_valid = false;            // d_tiles / d_blk_tile hold what h_tiles / h_blk_tile say
     bool timed = false;
-    hipStream_t last_stream = nullptr;
     bool deep = false;           // which build of the kernel this scene runs (KernelCfg)
     int slots = 0, wpg = 1;      // its slots per wavefront and wavefronts per workgroup
 };
@@ -1981,6 +1997,50 @@ int scratch_address(int dev, unsigned char **out) {
     return RT_OK;
 }
 
+// Per-slot state, work counter and cold-argument block of one set (the tables and the shares grow with the launches).
+int alloc_ctx(rt_scene *s, LaunchCtx &c) {
+    if (c.allocated) return RT_OK;
+    hipError_t e = hipSuccess;
+    if (s->ovf_depth > 0) e = hipMalloc(&c.ovf, (size_t)s->ovf_depth * s->n_slots * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&c.lstate, (size_t)LS_WORDS * s->n_slots * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&c.d_counter, 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&c.d_cold, sizeof(ColdArgs));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ev_tables, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming);
+    if (e != hipSuccess) return fail(RT_E_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
+    c.allocated = true;
+    return RT_OK;
+}
+
+// The set of per-launch state for a launch on `stream`: the one last used on that stream (launches on one stream run one
+// after the other anyway), else one not in use yet, else the one used longest ago -- whose launch this one then waits for.
+// `first_only`: callers that may not allocate, or that use the first set by contract (explicit rays, the entry point that
+// allocates nothing).  On return the stream is ordered behind the set's previous launch.
+int acquire_ctx(rt_scene *s, hipStream_t stream, bool first_only, LaunchCtx **out) {
+    int pick = -1;
+    if (first_only) pick = 0;
+    for (int k = 0; k < N_CTX && pick < 0; k++)
+        if (s->ctx[k].used && s->ctx[k].stream == stream) pick = k;
+    for (int k = 0; k < N_CTX && pick < 0; k++)
+        if (!s->ctx[k].used) pick = k;
+    if (pick < 0) {
+        pick = 0;
+        for (int k = 1; k < N_CTX; k++)
+            if (s->ctx[k].seq < s->ctx[pick].seq) pick = k;
+    }
+    LaunchCtx &c = s->ctx[pick];
+    if (!c.allocated) {
+        const int rc = alloc_ctx(s, c);
+        if (rc) return rc;
+    }
+    if (c.used && c.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, c.ev_done, 0));
+    c.used = true;
+    c.stream = stream;
+    c.seq = ++s->launches;
+    *out = &c;
+    return RT_OK;
+}
+
 int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n_tiles, const rt_params *p, double *d_rgb,
                   int *d_prim, hipStream_t stream) {
     int rc = check_params(cam, p);
@@ -2005,49 +2065,56 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         if (blocks > 0xF00000LL) return fail(RT_E_LIMIT, "too many pixel blocks in one launch");
     }
     HIP_TRY(hipSetDevice(s->dev));
-    if (n_tiles > s->tiles_cap) {
-        if (s->d_tiles) HIP_TRY(hipFree(s->d_tiles));
-        s->d_tiles = nullptr;
-        s->tiles_cap = 0;
-        HIP_TRY(hipMalloc((void **)&s->d_tiles, sizeof(DevTile) * (size_t)n_tiles));
-        s->tiles_cap = n_tiles;
-        s->tables_valid = false;
+    LaunchCtx *cp = nullptr;
+    rc = acquire_ctx(s, stream, false, &cp);
+    if (rc) return rc;
+    LaunchCtx &c = *cp;
+    if (n_tiles > c.tiles_cap) {
+        if (c.d_tiles) HIP_TRY(hipFree(c.d_tiles));
+        c.d_tiles = nullptr;
+        c.tiles_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c.d_tiles, sizeof(DevTile) * (size_t)n_tiles));
+        c.tiles_cap = n_tiles;
+        c.tables_valid = false;
     }
-    if (blocks > s->blk_cap) {
-        if (s->d_blk_tile) HIP_TRY(hipFree(s->d_blk_tile));
-        s->d_blk_tile = nullptr;
-        s->blk_cap = 0;
-        HIP_TRY(hipMalloc((void **)&s->d_blk_tile, sizeof(int) * (size_t)blocks));
-        s->blk_cap = blocks;
-        s->tables_valid = false;
+    if (blocks > c.blk_cap) {
+        if (c.d_blk_tile) HIP_TRY(hipFree(c.d_blk_tile));
+        c.d_blk_tile = nullptr;
+        c.blk_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c.d_blk_tile, sizeof(int) * (size_t)blocks));
+        c.blk_cap = blocks;
+        c.tables_valid = false;
     }
-    if (!s->tables_valid || s->h_tiles.size() != ht.size() || memcmp(s->h_tiles.data(), ht.data(), sizeof(DevTile) * ht.size()) != 0) {
-        s->tables_valid = false; // until both copies are queued
-        s->h_tiles = ht; // the copies below read members of *s, which stay alive until the next call
-        s->h_blk_tile.resize((size_t)blocks);
+    if (!c.tables_valid || c.h_tiles.size() != ht.size() || memcmp(c.h_tiles.data(), ht.data(), sizeof(DevTile) * ht.size()) != 0) {
+        c.tables_valid = false; // until both copies are queued
+        // the copies below read members of the set: the previous upload must have read them before they change
+        if (c.tables_stream_set) HIP_TRY(hipEventSynchronize(c.ev_tables));
+        c.h_tiles = ht;
+        c.h_blk_tile.resize((size_t)blocks);
         for (int i = 0; i < n_tiles; i++) {
             const long long end = i + 1 < n_tiles ? ht[i + 1].blk_first : blocks;
-            for (long long b = ht[i].blk_first; b < end; b++) s->h_blk_tile[(size_t)b] = i;
+            for (long long b = ht[i].blk_first; b < end; b++) c.h_blk_tile[(size_t)b] = i;
         }
-        HIP_TRY(hipMemcpyAsync(s->d_blk_tile, s->h_blk_tile.data(), sizeof(int) * (size_t)blocks, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(s->d_tiles, s->h_tiles.data(), sizeof(DevTile) * ht.size(), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipEventRecord(s->ev_tables, stream));
-        s->tables_stream = stream;
-        s->tables_valid = true;
-    } else if (stream != s->tables_stream) {
+        HIP_TRY(hipMemcpyAsync(c.d_blk_tile, c.h_blk_tile.data(), sizeof(int) * (size_t)blocks, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c.d_tiles, c.h_tiles.data(), sizeof(DevTile) * ht.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(c.ev_tables, stream));
+        c.tables_stream = stream;
+        c.tables_stream_set = true;
+        c.tables_valid = true;
+    } else if (stream != c.tables_stream) {
         // the cached tables were uploaded on another stream: this launch must not start before they have landed
-        HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables, 0));
+        HIP_TRY(hipStreamWaitEvent(stream, c.ev_tables, 0));
     }
-    if ((size_t)off > s->sub_cap) {
-        if (s->d_sub) HIP_TRY(hipFree(s->d_sub));
-        if (s->d_subcnt) HIP_TRY(hipFree(s->d_subcnt));
-        s->d_sub = nullptr; s->d_subcnt = nullptr; s->sub_cap = 0;
-        HIP_TRY(hipMalloc((void **)&s->d_sub, (size_t)off * 12 * sizeof(double)));
-        HIP_TRY(hipMalloc((void **)&s->d_subcnt, (size_t)off * sizeof(unsigned)));
-        s->sub_cap = (size_t)off;
+    if ((size_t)off > c.sub_cap) {
+        if (c.d_sub) HIP_TRY(hipFree(c.d_sub));
+        if (c.d_subcnt) HIP_TRY(hipFree(c.d_subcnt));
+        c.d_sub = nullptr; c.d_subcnt = nullptr; c.sub_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c.d_sub, (size_t)off * 12 * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&c.d_subcnt, (size_t)off * sizeof(unsigned)));
+        c.sub_cap = (size_t)off;
     }
-    HIP_TRY(hipMemsetAsync(s->d_subcnt, 0, (size_t)off * sizeof(unsigned), stream));
-    HIP_TRY(hipMemsetAsync(s->d_counter, 0, 16, stream));
+    HIP_TRY(hipMemsetAsync(c.d_subcnt, 0, (size_t)off * sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(c.d_counter, 0, 16, stream));
     const DevCamera dc = make_camera(cam);
     int grid_cap = 0;
     const KernelFn kern = render_kernel(s, p, &grid_cap);
@@ -2055,16 +2122,18 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     HIP_TRY(hipEventRecord(s->ev0, stream));
     ColdArgs ca = s->cold;
     ca.cam = dc; ca.P = *p;
-    ca.tiles = s->d_tiles; ca.blk_tile = s->d_blk_tile; ca.counter = s->d_counter;
-    ca.rgb = d_rgb; ca.prim = d_prim; ca.subbuf = s->d_sub; ca.subcnt = s->d_subcnt;
+    ca.tiles = c.d_tiles; ca.blk_tile = c.d_blk_tile; ca.counter = c.d_counter;
+    ca.rgb = d_rgb; ca.prim = d_prim; ca.subbuf = c.d_sub; ca.subcnt = c.d_subcnt;
     ca.n_work = (unsigned)(blocks * 256); ca.n_tiles = n_tiles;
-    hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, stream, ca, s->d_cold);
+    hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, stream, ca, c.d_cold);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, stream, s->d, (const ColdArgs *)s->d_cold, s->d_stats);
+    DevScene dsc = s->d;
+    dsc.ovf = (unsigned *)c.ovf; dsc.lstate = (double *)c.lstate;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, stream, dsc, (const ColdArgs *)c.d_cold, s->d_stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
+    HIP_TRY(hipEventRecord(c.ev_done, stream));
     s->timed = true;
-    s->last_stream = stream;
     return RT_OK;
 }
 
@@ -2401,16 +2470,16 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         rt_free_scene(s);
         return fail(RT_E_LIMIT, "tree too deep: traversal stack of %d levels (max %u)", need_depth, ST_SP);
     }
-    hipError_t e = hipSuccess;
-    if (ovf_depth > 0) e = hipMalloc(&s->ovf, (size_t)ovf_depth * n_slots * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc(&s->lstate, (size_t)LS_WORDS * n_slots * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_counter, 16);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_cold, sizeof(ColdArgs));
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, N_STATS * sizeof(unsigned long long));
+    s->ovf_depth = ovf_depth;
+    s->n_slots = n_slots;
+    if (alloc_ctx(s, s->ctx[0]) != RT_OK) { // the first set of per-launch state; a second stream brings the second
+        rt_free_scene(s);
+        return RT_E_DEVICE;
+    }
+    hipError_t e = hipMalloc((void **)&s->d_stats, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&s->ev0);
     if (e == hipSuccess) e = hipEventCreate(&s->ev1);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_tables, hipEventDisableTiming);
     if (e != hipSuccess) {
         rt_free_scene(s);
         return fail(RT_E_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
@@ -2421,8 +2490,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->cold.sph = (const SphGeom *)s->sph;
     s->cold.sshade = (const SphShade *)s->sshade;
     s->cold.tex = n_textri ? (const unsigned char *)s->tex : nullptr;
-    s->d.ovf = (unsigned *)s->ovf;
-    s->d.lstate = (double *)s->lstate;
+    s->d.ovf = nullptr; s->d.lstate = nullptr; // per launch
     s->cold.reach = std::sqrt(lg2) * 1.000001;
     s->cold.absn = 0;
     for (int k = 0; k < 3; k++) {
@@ -2456,12 +2524,18 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->lights, s->ovf, s->lstate, s->lhdr, s->d_counter, s->d_cold, s->d_stats, s->d_tiles, s->d_sub, s->d_subcnt, s->d_blk_tile, s->d_stage_rgb, s->d_stage_prim};
+    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->lights, s->lhdr, s->d_stats, s->d_stage_rgb, s->d_stage_prim};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (LaunchCtx &c : s->ctx) {
+        void *own[] = {c.ovf, c.lstate, c.d_counter, c.d_cold, c.d_tiles, c.d_sub, c.d_subcnt, c.d_blk_tile};
+        for (void *p : own)
+            if (p) (void)hipFree(p);
+        if (c.ev_tables) (void)hipEventDestroy(c.ev_tables);
+        if (c.ev_done) (void)hipEventDestroy(c.ev_done);
+    }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
-    if (s->ev_tables) (void)hipEventDestroy(s->ev_tables);
     delete s;
     return RT_OK;
 }
@@ -2504,6 +2578,9 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
     rc = scratch_address(s->dev, &scr);
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
+    LaunchCtx *cp = nullptr; // the rays' per-slot state is the first set's, which rt_upload_scene allocated
+    rc = acquire_ctx(s, stream, true, &cp);
+    if (rc) return rc;
     // the array keeps the previous call's contents: the per-pixel counts must start at zero (the set-up kernel
     // rewrites the tables and the work counter; the shares are written before they are read)
     HIP_TRY(hipMemsetAsync(scr + NA_OFF_CNT, 0, (size_t)off * sizeof(unsigned), stream));
@@ -2521,18 +2598,21 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
     ca.n_work = (unsigned)(blocks * 256); ca.n_tiles = n_tiles;
     hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, stream, ca, (ColdArgs *)(scr + NA_OFF_COLD));
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, stream, s->d, (const ColdArgs *)(scr + NA_OFF_COLD), s->d_stats);
+    DevScene dsc = s->d;
+    dsc.ovf = (unsigned *)cp->ovf; dsc.lstate = (double *)cp->lstate;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, stream, dsc, (const ColdArgs *)(scr + NA_OFF_COLD), s->d_stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
+    HIP_TRY(hipEventRecord(cp->ev_done, stream));
     s->timed = true;
-    s->last_stream = stream;
     return RT_OK;
 }
 
 int rt_get_stats(rt_scene *s, rt_stats *stats) {
     if (!s || !stats) return fail(RT_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(s->dev));
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    for (LaunchCtx &c : s->ctx) // every launch in flight adds to the same counters
+        if (c.used) HIP_TRY(hipEventSynchronize(c.ev_done));
     unsigned long long h[N_STATS];
     HIP_TRY(hipMemcpy(h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(s->d_stats, 0, sizeof(h)));
@@ -2623,6 +2703,9 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     }
     double *d_rays = nullptr, *d_tt = nullptr, *d_st = nullptr;
     int *d_ti = nullptr, *d_si = nullptr;
+    LaunchCtx *cp = nullptr;
+    const int rc = acquire_ctx(s, nullptr, true, &cp);
+    if (rc) return rc;
     hipError_t e = hipMalloc((void **)&d_rays, (size_t)n * 6 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&d_tt, (size_t)n * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&d_st, (size_t)n * sizeof(double));
@@ -2630,19 +2713,21 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) e = hipMalloc((void **)&d_si, (size_t)n * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(s->d_counter, 0, 16);
+    if (e == hipSuccess) e = hipMemset(cp->d_counter, 0, 16);
     if (e == hipSuccess) {
         const long long want = (n + s->slots * s->wpg - 1) / (s->slots * s->wpg);
         const int grid = (int)std::min<long long>(s->grid_trace, want); // stay within the slot count the state arrays were sized for
         const KernelFn kern = pick_kernel<true>(s->d.sph_root != 0, s->deep, false);
         ColdArgs ca = s->cold;
         ca.P = rt_params{1, 0, 0, 0, 1, 0, 0, 0, 0};
-        ca.counter = s->d_counter; ca.n_work = (unsigned)n;
+        ca.counter = cp->d_counter; ca.n_work = (unsigned)n;
         ca.rays = d_rays; ca.tri_id = d_ti; ca.tri_t = d_tt; ca.sph_id = d_si; ca.sph_t = d_st;
-        hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, nullptr, ca, s->d_cold);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, nullptr, s->d, (const ColdArgs *)s->d_cold, s->d_stats);
+        DevScene dsc = s->d;
+        dsc.ovf = (unsigned *)cp->ovf; dsc.lstate = (double *)cp->lstate;
+        hipLaunchKernelGGL(k_put_cold, dim3(1), dim3(1), 0, nullptr, ca, cp->d_cold);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, nullptr, dsc, (const ColdArgs *)cp->d_cold, s->d_stats);
         e = hipGetLastError();
-        s->last_stream = nullptr;
+        if (e == hipSuccess) e = hipEventRecord(cp->ev_done, nullptr);
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(tri_id, d_ti, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);

@@ -124,6 +124,68 @@ class FrameRenderer:
         return self.assemble()
 
 
+class FramePipeline:
+    """Several frames of one scene in flight on this rank: frame i goes to slot i % depth, and every slot has its own
+    FrameRenderer (share, gather and frame buffers) and its own stream, over ONE DeviceScene -- the library keeps two
+    sets of per-launch state per scene, so launches on two streams overlap: one frame's last paths (a few long ones
+    keep a few wavefronts busy) run beside the next frame's first, and a frame's gather beside the next frame's
+    kernel.  A short frame -- one rank's share of a frame split eight ways -- gains most.  The frames are the same,
+    bit for bit, as FrameRenderer's: a path's random stream depends only on (seed, pixel, sub-pixel, sample).
+
+    With torch.distributed every rank must submit the same frames in the same order (each submit issues the slot's
+    gather).  A slot's frame stays valid until the slot is submitted to again: take it with frame(slot) first."""
+
+    def __init__(self, scene, cam, params, depth=2, **renderer_args):
+        import torch
+        self.torch = torch
+        depth = max(1, int(depth))
+        self.renderers = [FrameRenderer(scene, cam, type(params).from_buffer_copy(params), **renderer_args) for _ in range(depth)]
+        self.device = self.renderers[0].device
+        on_gpu = self.device.type == "cuda"
+        if depth == 1 or not on_gpu:  # one frame at a time: the caller's stream
+            self.streams = [None] * depth
+        else:
+            self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
+            for st in self.streams:  # whatever the caller queued before (uploads, clears) comes first
+                st.wait_stream(torch.cuda.current_stream(self.device))
+        self.depth = depth
+        self.submitted = 0
+
+    def _on(self, slot):
+        import contextlib
+        st = self.streams[slot]
+        return self.torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
+
+    def submit(self, seed=None, kernel_events=None):
+        """Queue the next frame (asynchronous) and return its slot.  kernel_events: a pair of torch events to record
+        around the kernel, on the stream it runs on."""
+        slot = self.submitted % self.depth
+        self.submitted += 1
+        fr = self.renderers[slot]
+        if seed is not None:
+            fr.params.seed = seed
+        with self._on(slot):
+            if kernel_events is not None:
+                kernel_events[0].record()
+            fr.launch()
+            if kernel_events is not None:
+                kernel_events[1].record()
+            fr.assemble()
+        return slot
+
+    def frame(self, slot):
+        """The slot's finished frame on rank 0 (None elsewhere); waits for it."""
+        self.wait(slot)
+        return self.renderers[slot].frame
+
+    def wait(self, slot=None):
+        for k in range(self.depth) if slot is None else [slot]:
+            if self.streams[k] is not None:
+                self.streams[k].synchronize()
+            elif self.device.type == "cuda":
+                self.torch.cuda.current_stream(self.device).synchronize()
+
+
 def assemble_host(sizex, sizey, shards, packed_per_rank, channels=3, dtype=np.float64):
     """numpy version of the un-permute step, for checks without a GPU."""
     frame = np.zeros((sizex, sizey, channels) if channels else (sizex, sizey), dtype=dtype)

@@ -1,6 +1,7 @@
 """Run by tests/test_gpu_rccl.py in a child process: a ONE-rank `nccl` (= RCCL) process group, rendezvous through a
 file, and a frame assembled through torch.distributed.gather on device tensors -- the exchange an N-GPU run does --
-compared with the plain single-launch render.  Prints OK on success."""
+compared with the plain single-launch render; then the same with two frames in flight on two streams.  Prints OK on
+success."""
 import os
 import sys
 import tempfile
@@ -34,6 +35,15 @@ def main():
     full, fpid, _ = dev.render_tile(cam, prm, 0, 0, sizex, sizey)
     assert np.array_equal(out.cpu().numpy(), full)
     assert np.array_equal(fr.ids.cpu().numpy(), fpid)
+    # two frames in flight, each with its own stream and gather, over the same scene: frame i is the frame of seed i
+    pipe = frame.FramePipeline(dev, cam, prm, 2, tile_rows=16, tile_cols=24, want_ids=True, collective=True)
+    slots = [pipe.submit(seed) for seed in (7, 8, 9, 10)]
+    assert slots == [0, 1, 0, 1]
+    for slot, seed in ((0, 9), (1, 10)):
+        prm.seed = seed
+        want, wid, _ = dev.render_tile(cam, prm, 0, 0, sizex, sizey)
+        assert np.array_equal(pipe.frame(slot).cpu().numpy(), want)
+        assert np.array_equal(pipe.renderers[slot].ids.cpu().numpy(), wid)
     dist.barrier()
     dist.destroy_process_group()
     dev.close()
