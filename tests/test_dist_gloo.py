@@ -56,8 +56,15 @@ def _worker(rank, world, port, out_path):
     fr = frame.FrameRenderer(OracleBackedScene(po.OracleScene(sc), po), cam, prm, 16, 16, rank=rank, world=world,
                              device=torch.device("cpu"), want_ids=True)
     out = fr.render()
+    # the same through the pipeline of frames in flight (on the CPU its slots share the caller's thread; what is
+    # covered here is the slots' bookkeeping and one gather per slot, in the same order on every rank)
+    pipe = frame.FramePipeline(OracleBackedScene(po.OracleScene(sc), po), cam, prm, 2, tile_rows=16, tile_cols=16, rank=rank,
+                               world=world, device=torch.device("cpu"), want_ids=True)
+    slots = [pipe.submit(seed) for seed in (5, 6, 7)]
+    assert slots == [0, 1, 0] and prm.seed == 5
     if rank == 0:
-        np.savez(out_path, rgb=out.numpy(), ids=fr.ids.numpy())
+        np.savez(out_path, rgb=out.numpy(), ids=fr.ids.numpy(), rgb6=pipe.frame(1).numpy(), rgb7=pipe.frame(0).numpy(),
+                 ids7=pipe.renderers[0].ids.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,6 +89,12 @@ def test_gather_assembles_the_same_frame(po, ra, tmp_path, world):
                                   0, 0, SIZEX, SIZEY)
     assert np.array_equal(got["rgb"], rgb)
     assert np.array_equal(got["ids"], ids)
+    for seed in (6, 7):
+        want, wids, _ = orc.render_tile(po.make_camera(sc["camera"]["o"], sc["camera"]["d"], SIZEX, SIZEY),
+                                        po.make_params(samps=1, rr_depth=3, rr_mode=1, split_depth=2, hard_depth=16, jitter=1, seed=seed),
+                                        0, 0, SIZEX, SIZEY)
+        assert np.array_equal(got[f"rgb{seed}"], want)
+    assert np.array_equal(got["ids7"], wids)
     assert (ids != po.MISS_ID).any()
 
 
