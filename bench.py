@@ -235,7 +235,7 @@ def main():
             if tj["workload"] == args.workload and "valu" in tj:
                 valu = dict(tj["valu"], measured_in_this_run=False)
         out = {
-            "metric": "Mrays/s (node), Sponza-class 4K depth-5" if args.workload == "sponza" else f"Mrays/s (node), {args.workload}",
+            "metric": "Mrays/s (node), Sponza-class 4K depth-5" if (args.workload, sizex, sizey) == ("sponza", 2160, 3840) else f"Mrays/s (node), {args.workload} {sizex}x{sizey}",
             "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
