@@ -115,7 +115,7 @@ def cpu_baseline(scene, cam_od, sizex, sizey, pkw, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=0)  # 0: 5 frames on one GPU, 5 per rank on several (a rank's share of a frame is short)
     ap.add_argument("--warmup", type=int, default=3)  # the engine clock needs about half a second of load to settle
     ap.add_argument("--workload", default="sponza")
     ap.add_argument("--sizex", type=int, default=0)
@@ -143,6 +143,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.steps <= 0:
+        args.steps = 5 * world
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     torch.cuda.set_device(local_rank)
