@@ -219,10 +219,11 @@ def main():
                      + per_launch["sph_tests"] * B_SPH)
         avg_ms = float(np.mean(kern_ms))
         # the render kernel instance the library picks at upload: sphere hierarchy or not; 140 slots with an
-        # 8-level stack ring for trees of 28 levels and more, else 152 with a 4-level ring; one wavefront per workgroup
+        # 8-level stack ring for trees of 28 levels and more, else 152 with a 4-level ring; one wavefront per workgroup;
+        # up to three triangles behind one culling box for the deep trees, two otherwise
         deep = int(host.desc.contents.tree_depth) >= int(os.environ.get("RT_HIP_DEEP_TREE", "28"))
         kernel_name = "k_main<false, %s, %d, %s>" % ("true" if host.num_spheres >= 16 else "false", 1 if host.desc.contents.n_textures else 0,
-                                                    "140, 8, 1" if deep else "152, 4, 1")
+                                                    "140, 8, 1, 3" if deep else "152, 4, 1, 2")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from hardware counters cannot be collected inside this process; the figure of the
         # last profiled full-size launch of the same workload is kept in bench_counters.json (how: its "source")

@@ -70,7 +70,16 @@ constexpr int WAVE = 64;          // threads per workgroup: one wavefront
 // many levels through HBM with the short ring.  RT_SLOTS / RT_LDS_STACK make both builds the same (test builds).
 // (Workgroups of two wavefronts could share 21 pieces, 159 slots each: 0.92 instead of 0.90 of the lanes busy per step,
 // but the same kernel runs 2 % slower in workgroups of two at equal slot count -- measured, no gain; RT_WPG keeps the option.)
-struct KernelCfg { int slots, ring, wpg; }; // wpg: wavefronts per workgroup (each with its own slots; they share nothing)
+// group: the most triangles a culling hierarchy keeps behind one box (2 to 4); the triangle step tests a group in one go.
+// Every further triangle makes that step longer for the whole wavefront: scenes of few large triangles (shallow trees)
+// do best with pairs, meshes of millions of small ones (deep trees, long own lists) with more.
+struct KernelCfg { int slots, ring, wpg, group; }; // wpg: wavefronts per workgroup (each with its own slots; they share nothing)
+#ifndef RT_GROUP_SHALLOW
+#define RT_GROUP_SHALLOW 2
+#endif
+#ifndef RT_GROUP_DEEP
+#define RT_GROUP_DEEP 3
+#endif
 #if defined(RT_SLOTS) || defined(RT_LDS_STACK)
 #ifndef RT_SLOTS
 #define RT_SLOTS 140
@@ -81,9 +90,9 @@ struct KernelCfg { int slots, ring, wpg; }; // wpg: wavefronts per workgroup (ea
 #ifndef RT_WPG
 #define RT_WPG 1
 #endif
-constexpr KernelCfg CFG_SHALLOW = {RT_SLOTS, RT_LDS_STACK, RT_WPG}, CFG_DEEP = {RT_SLOTS, RT_LDS_STACK, RT_WPG};
+constexpr KernelCfg CFG_SHALLOW = {RT_SLOTS, RT_LDS_STACK, RT_WPG, RT_GROUP_SHALLOW}, CFG_DEEP = {RT_SLOTS, RT_LDS_STACK, RT_WPG, RT_GROUP_DEEP};
 #else
-constexpr KernelCfg CFG_SHALLOW = {152, 4, 1}, CFG_DEEP = {140, 8, 1};
+constexpr KernelCfg CFG_SHALLOW = {152, 4, 1, RT_GROUP_SHALLOW}, CFG_DEEP = {140, 8, 1, RT_GROUP_DEEP};
 #endif
 constexpr int DEEP_TREE = 28; // tree depth from which the 8-level ring is used
 // a wavefront's slots in the per-slot arrays in HBM: whole 128-byte lines, so that no two wavefronts write one line
@@ -192,6 +201,7 @@ struct DevScene {
     unsigned *ovf;  // overflow stack [ovf_depth][n_slots]
     double *lstate; // per-slot state kept in HBM [LS_WORDS][n_slots]
     unsigned g_list; // granule of node 0's list record
+    unsigned g_tri;  // granule of the first triangle record (five granules each, in list order)
     unsigned g_sphc; // granule of the sphere hierarchy's first cull record (the triangles' records lie below it)
     unsigned g_sph;  // granule of sphere 0's copy in the pool (two granules per sphere); tri items from here on are spheres
     unsigned sph_root; // item of the sphere hierarchy's root record, 0 = spheres are scanned in the shade step
@@ -449,16 +459,16 @@ __device__ __forceinline__ void sincos_2pi(double x, double &sn, double &cs) {
 //   cull item   : IT_CULL | granule                          one inner record of a list's hierarchy
 //   tri item    : IT_TRI | chain << 28 | granule (28 bits)   one exact triangle test; with `chain` the next
 //                 triangle of the list follows directly, up to the one marked last (short lists)
-//   pair item   : IT_PAIR | granule (28 bits)                 two triangles that follow each other in the pool (a range
-//                 of two in a list's hierarchy, behind ONE box), tested in one step: a second test costs a fifth of
-//                 a step of its own
+//   group item  : IT_GROUP | (n - 2) << 26 | position (26 bits)  n = 2 to 4 triangles that follow each other in the pool
+//                 from that list position on (a small range of a list's hierarchy, behind ONE box), tested in one step:
+//                 a further test costs a fifth of a step of its own
 //   after item  : IT_AFTER | flag << 30 | far << 28 | node granule (28 bits); far: 0 none, 1 left, 2 right child,
 //                 3 = a far child whose box the ray is certain to miss (visited in name only)
 //                 the node's near child is done: own list, then the far child; `flag` is the
 //                 enclosing frame's "has a hit" so far.  Its record is the node's ListRec.
 constexpr unsigned IT_CULL = 1u << 29, IT_TRI = 2u << 29, IT_CHAIN = 1u << 28, IT_AFTER = 1u << 31, IDX29 = 0x1FFFFFFFu,
                    IDX28 = 0x0FFFFFFFu;
-constexpr unsigned IT_PAIR = 3u << 29;
+constexpr unsigned IT_GROUP = 3u << 29, GROUP_POS = 0x03FFFFFFu;
 constexpr unsigned TRI_LAST = 0x80000000u; // in TriRec::pos: last triangle of its own list
 constexpr unsigned IT_END = 0xFFFFFFFFu; // "the stack is empty": the traversal is complete
 // A node-kind item no node can have: "the next stack levels are in HBM".  The step that runs it fetches
@@ -517,7 +527,7 @@ __device__ __forceinline__ unsigned item_kind(unsigned x) {
 //     node   enter a kd-tree node: check_aabb, choose near / far child          (kdtree.cpp:111-141)
 //     cull   four child boxes of an own list's culling hierarchy; the first such step of a list
 //            also does the bookkeeping of "the node's near child has returned"   (kdtree.cpp:122-125)
-//     tri    one exact triangle test, or two for a pair item                    (kdtree.cpp:101-107)
+//     tri    one exact triangle test, or those of a group item                  (kdtree.cpp:101-107)
 //     shade  sphere scan, material, next ray / next path / next pixel           (raytrace.cpp:41-95,196-205)
 // A wavefront owns SLOTS ray slots (152, or 140 in the build for deep trees).  A slot is a complete path tracer
 // state: its ray origin and inverse direction, its current item, flags and the top of its
@@ -541,10 +551,10 @@ __device__ __forceinline__ float exp_up_get(unsigned char e) { return __uint_as_
 __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30f), 1e30f); }
 
 // SPH = true: the scene has a sphere hierarchy (a second instance, so that scenes without one do not pay for it).
-// SLOTS, LDS_STACK, WPG: see KernelCfg.
+// SLOTS, LDS_STACK, WPG, GROUP: see KernelCfg.
 // FEAT selects what the shade step can do beyond the reference's untextured integrator (instances of their own, like
 // SPH): 1 = textured triangles, 2 = those and explicit light sampling (rt_params.light_mode 1).
-template <bool TRACE, bool SPH, int FEAT, int SLOTS, int LDS_STACK, int WPG>
+template <bool TRACE, bool SPH, int FEAT, int SLOTS, int LDS_STACK, int WPG, int GROUP>
 #ifndef RT_KALIGN
 #define RT_KALIGN 256
 #endif
@@ -1022,26 +1032,36 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         } else if (pick == K_TRI) {
             RT_MARK("tri");
             bool is_sph = false;
-            if (run) { // ---- one exact triangle test (kdtree.cpp:105), a pair's second one further down
-                const double2 *p = (const double2 *)(S.pool + (size_t)(cur & IDX28) * 16);
+            if (run) { // ---- one exact triangle test (kdtree.cpp:105), a group's further ones below
+                // a group's further triangles follow the first in the pool (a lane with fewer reads its first record
+                // again: a load under a branch of its own would be waited for separately)
+                const bool grp = (cur >> 29) == 3u;
+                const unsigned gn = grp ? ((cur >> 26) & 3u) + 2u : 1u; // triangles of this step
+                const double2 *p = (const double2 *)(S.pool + (size_t)(grp ? S.g_tri + 5u * (cur & GROUP_POS) : (cur & IDX28)) * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
                 const long long w9 = __double_as_longlong(q4.y);
-                // a pair's second triangle (the others read their own record again: a load under a branch of its own
-                // would be waited for separately)
-                const bool pair = (cur >> 29) == 3u;
-                const double2 *pb = p + (pair ? 5 : 0);
-                const double2 u0 = pb[0], u1 = pb[1], u2 = pb[2], u3 = pb[3], u4 = pb[4];
+                double2 u[GROUP - 1][5];
+#pragma unroll
+                for (int k = 1; k < GROUP; k++) {
+                    const double2 *pk = p + (gn > (unsigned)k ? 5 * k : 0);
+#pragma unroll
+                    for (int i = 0; i < 5; i++) u[k - 1][i] = pk[i];
+                }
+                const bool chain = (cur >> 28) == ((IT_TRI | IT_CHAIN) >> 28);
                 const d3 d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
                 const double best_t = ls[LS_BT * lss];
                 const double2 a = sA[sl], b = sB[sl];
-                is_sph = SPH && (cur & IDX28) >= S.g_sph;
+                is_sph = SPH && !grp && (cur & IDX28) >= S.g_sph;
                 double sph_ts = 0; // the nearest sphere so far, fetched with the record
                 if (SPH && is_sph) sph_ts = ls[LS_ST * lss];
 #ifndef RT_NO_CONSUME
                 if (SPH) asm volatile("" : : "v"(sph_ts));
                 asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q1.x), "v"(q1.y), "v"(q2.x), "v"(q2.y), "v"(q3.x), "v"(q3.y), "v"(q4.x), "v"(q4.y),
                              "v"(d.x), "v"(d.y), "v"(d.z), "v"(best_t)); // (delivery taken on every path, see the cull step)
-                asm volatile("" : : "v"(u0.x), "v"(u0.y), "v"(u1.x), "v"(u1.y), "v"(u2.x), "v"(u2.y), "v"(u3.x), "v"(u3.y), "v"(u4.x), "v"(u4.y));
+#pragma unroll
+                for (int k = 0; k < GROUP - 1; k++)
+                    asm volatile("" : : "v"(u[k][0].x), "v"(u[k][0].y), "v"(u[k][1].x), "v"(u[k][1].y), "v"(u[k][2].x), "v"(u[k][2].y), "v"(u[k][3].x),
+                                 "v"(u[k][3].y), "v"(u[k][4].x), "v"(u[k][4].y));
 #endif
                 const d3 o = mk(a.x, a.y, b.x);
                 if (is_sph) { // ---- one sphere of the sphere hierarchy (sphere.h:13-21, sphere.cpp:7)
@@ -1065,55 +1085,57 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     }
                     want_pop = true;
                 }
+                // the step's triangles in turn, each against what the ones before left behind; the slot's state is
+                // written once, by the last one that won
+                double best_cur = best_t;
+                unsigned new_ha = 0;
+                bool have_new = false;
+                auto consider = [&](double t, long long w) __attribute__((always_inline)) {
+                    if (t > EPS) {
+                        // strict < keeps the earlier of two equal distances; inside one list "earlier"
+                        // is the lower rank, across lists it is the list visited first
+                        bool better = t < best_cur;
+                        if (__builtin_expect(t == best_cur && t < 1e20, 0)) { // rare: the two triangles' lists and ranks decide
+                            const unsigned held = have_new ? new_ha : ((const unsigned *)&ls[LS_HA * lss])[0];
+                            const uint2 lb = S.tlist[held], lc = S.tlist[(unsigned)w & ~TRI_LAST];
+                            better = lb.x == lc.x && (int)(w >> 32) < (int)lb.y;
+                        }
+                        if (better) { best_cur = t; new_ha = (unsigned)w & ~TRI_LAST; have_new = true; }
+                        if (t < 1e10) st |= ST_FLAG;
+                    }
+                };
                 const double t = is_sph ? 0.0 : tri_hit(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d);
-                if (t > EPS) {
-                    const int rk = (int)(w9 >> 32);
-                    // strict < keeps the earlier of two equal distances; inside one list "earlier"
-                    // is the lower rank, across lists it is the list visited first
-                    bool better = t < best_t;
-                    if (__builtin_expect(t == best_t && t < 1e20, 0)) { // rare: the two triangles' lists and ranks decide
-                        const uint2 lb = S.tlist[((const unsigned *)&ls[LS_HA * lss])[0]], lc = S.tlist[(unsigned)w9 & ~TRI_LAST];
-                        better = lb.x == lc.x && rk < (int)lb.y;
-                    }
-                    if (better) {
-                        ls[LS_BT * lss] = t;
-                        sT[sl] = half_up_put((float)t * 1.000001f); // (t > 0; the factor covers the rounding to single)
-                        ls[LS_HA * lss] = __longlong_as_double((long long)(unsigned long long)((unsigned)w9 & ~TRI_LAST));
-                    }
-                    if (t < 1e10) st |= ST_FLAG;
+                consider(t, w9);
+#pragma unroll
+                for (int k = 1; k < GROUP; k++) {
+                    const bool has = gn > (unsigned)k;
+                    const double2 *r = u[k - 1];
+                    if (__ballot(has))
+                        consider(has ? tri_hit(mk(r[0].x, r[0].y, r[1].x), mk(r[1].y, r[2].x, r[2].y), mk(r[3].x, r[3].y, r[4].x), o, d) : 0.0, __double_as_longlong(r[4].y));
                 }
-                if (__ballot(pair)) { // the pair's second triangle, against what the first left behind
-                    const long long w9b = __double_as_longlong(u4.y);
-                    const double tb = pair ? tri_hit(mk(u0.x, u0.y, u1.x), mk(u1.y, u2.x, u2.y), mk(u3.x, u3.y, u4.x), o, d) : 0.0;
-                    if (tb > EPS) {
-                        const bool a_won = t > EPS && t < best_t; // (a tie of the first went through the rare block above: read the state again there)
-                        double best_b = a_won ? t : best_t;
-                        bool better = tb < best_b;
-                        if (__builtin_expect(tb == best_b && tb < 1e20, 0)) {
-                            const uint2 lb = S.tlist[((const unsigned *)&ls[LS_HA * lss])[0]], lc = S.tlist[(unsigned)w9b & ~TRI_LAST];
-                            better = lb.x == lc.x && (int)(w9b >> 32) < (int)lb.y;
-                        }
-                        if (better) {
-                            ls[LS_BT * lss] = tb;
-                            sT[sl] = half_up_put((float)tb * 1.000001f);
-                            ls[LS_HA * lss] = __longlong_as_double((long long)(unsigned long long)((unsigned)w9b & ~TRI_LAST));
-                        }
-                        if (tb < 1e10) st |= ST_FLAG;
-                    }
+                if (have_new) {
+                    ls[LS_BT * lss] = best_cur;
+                    sT[sl] = half_up_put((float)best_cur * 1.000001f); // (t > 0; the factor covers the rounding to single)
+                    ls[LS_HA * lss] = __longlong_as_double((long long)(unsigned long long)new_ha);
                 }
                 if (is_sph) {}
-                else if ((cur & IT_CHAIN) && !((unsigned)w9 & TRI_LAST)) next = cur + 5u; // the list's next triangle
+                else if (chain && !((unsigned)w9 & TRI_LAST)) next = cur + 5u; // the list's next triangle
                 else want_pop = true;
 #ifdef RT_PROFILE
-                p_tri[0] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) != 0));          // tests of short lists
-                p_tri[1] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) != 0 && t > EPS)); // ... that hit
-                p_tri[2] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) == 0));          // tests behind culling boxes
-                p_tri[3] += (unsigned)__popcll(__ballot((cur & IT_CHAIN) == 0 && t > EPS)); // ... that hit
+                p_tri[0] += (unsigned)__popcll(__ballot(chain));                 // steps of short lists
+                p_tri[1] += (unsigned)__popcll(__ballot(chain && t < 1e10));     // ... whose (first) triangle is hit
+                p_tri[2] += (unsigned)__popcll(__ballot(!chain));                // steps behind culling boxes
+                p_tri[3] += (unsigned)__popcll(__ballot(!chain && t < 1e10));    // ... whose (first) triangle is hit
 #endif
             }
             RT_EV(9, run); RT_EV(10, run && (st & ST_FLAG));
             const int nsph = (int)__popcll(__ballot(is_sph));
-            RT_SCOUNT(c_done, nrun - nsph + (int)__popcll(__ballot(run && (cur >> 29) == 3u)));
+            {
+                int extra = 0; // a group's further triangles
+#pragma unroll
+                for (int k = 1; k < GROUP; k++) extra += (int)__popcll(__ballot(run && (cur >> 29) == 3u && ((cur >> 26) & 3u) + 2u > (unsigned)k));
+                RT_SCOUNT(c_done, nrun - nsph + extra);
+            }
             RT_SCOUNT(c_sphdone, nsph);
         } else {
             RT_MARK("shade");
@@ -1632,9 +1654,10 @@ struct rt_scene {
 using KernelFn = void (*)(DevScene, const ColdArgs *, unsigned long long *);
 template <bool TRACE, int FEAT>
 KernelFn pick_kernel2(bool sph, bool deep) {
-    if (deep) return sph ? k_main<TRACE, true, FEAT, CFG_DEEP.slots, CFG_DEEP.ring, CFG_DEEP.wpg> : k_main<TRACE, false, FEAT, CFG_DEEP.slots, CFG_DEEP.ring, CFG_DEEP.wpg>;
-    return sph ? k_main<TRACE, true, FEAT, CFG_SHALLOW.slots, CFG_SHALLOW.ring, CFG_SHALLOW.wpg>
-               : k_main<TRACE, false, FEAT, CFG_SHALLOW.slots, CFG_SHALLOW.ring, CFG_SHALLOW.wpg>;
+    if (deep) return sph ? k_main<TRACE, true, FEAT, CFG_DEEP.slots, CFG_DEEP.ring, CFG_DEEP.wpg, CFG_DEEP.group>
+                         : k_main<TRACE, false, FEAT, CFG_DEEP.slots, CFG_DEEP.ring, CFG_DEEP.wpg, CFG_DEEP.group>;
+    return sph ? k_main<TRACE, true, FEAT, CFG_SHALLOW.slots, CFG_SHALLOW.ring, CFG_SHALLOW.wpg, CFG_SHALLOW.group>
+               : k_main<TRACE, false, FEAT, CFG_SHALLOW.slots, CFG_SHALLOW.ring, CFG_SHALLOW.wpg, CFG_SHALLOW.group>;
 }
 // (explicit-ray queries never shade: they have only the plain instance)
 template <bool TRACE>
@@ -1649,8 +1672,9 @@ KernelFn pick_kernel(bool sph, bool deep, bool tex, bool lights = false) {
 namespace {
 
 // Culling hierarchy for one long own list: median splits of the triangle centroids along the
-// widest axis, two levels per record, down to single triangles and pairs (a range of two is not split: its two
-// triangles share a box and a step, which measured 7 % faster than a box and a step each).  Every record holds the boxes of
+// widest axis, two levels per record, down to single triangles and groups (a range of up to KernelCfg::group triangles
+// is not split: they share a box and a triangle step, which measured 7 % faster at 4K with pairs than a box and a step
+// each).  Every record holds the boxes of
 // its (up to four) children (exact bounds rounded OUTWARD to single precision) and the children as
 // work items, so one 128-byte fetch decides four subtrees and a triangle is only fetched when its
 // own box is met.  The root of a list's hierarchy is stored in the node's list record.
@@ -1668,6 +1692,7 @@ struct CullBuild {
     int max_depth;
     unsigned leaf_stride = 5;     // granules per leaf record
     bool by_src = false;          // leaves are addressed by their source index (spheres) instead of their list position
+    int group = 1;                // the most triangles behind one box (KernelCfg::group); 1: every leaf has its own
 };
 
 // Splits the range [a, b) (b - a >= 2) in two and returns the split point: the plane between 16
@@ -1743,9 +1768,9 @@ void cull_fill(CullBuild &B, int a, int b, int depth, QuadRec &q, double lo[3], 
     std::vector<CullTri> &bt = *B.bt;
     int r[5], nr = 0; // child range boundaries
     r[nr++] = a;
-    if (b - a >= 2) { // a list of one triangle gets a record with one child
+    if (b - a > B.group) { // (a list of one triangle gets a record with one child, a list that fits a group one group)
         const int mid = cull_split(bt, a, b);
-        const int keep = B.by_src ? 2 : 3; // two triangles stay together: a pair item behind one box
+        const int keep = B.group + 1; // what fits a group stays together: one item behind one box
         if (mid - a >= keep) r[nr++] = cull_split(bt, a, mid);
         r[nr++] = mid;
         if (b - mid >= keep) r[nr++] = cull_split(bt, mid, b);
@@ -1759,9 +1784,11 @@ void cull_fill(CullBuild &B, int a, int b, int depth, QuadRec &q, double lo[3], 
         if (cb - ca == 1) {
             for (int k = 0; k < 3; k++) { cl[c][k] = bt[ca].lo[k]; ch[c][k] = bt[ca].hi[k]; }
             q.item[c] = IT_TRI | (B.tri_base + B.leaf_stride * (unsigned)(B.by_src ? bt[ca].src : B.first + ca));
-        } else if (cb - ca == 2 && !B.by_src) { // two triangles behind one box, neighbours in the pool
-            for (int k = 0; k < 3; k++) { cl[c][k] = std::min(bt[ca].lo[k], bt[ca + 1].lo[k]); ch[c][k] = std::max(bt[ca].hi[k], bt[ca + 1].hi[k]); }
-            q.item[c] = IT_PAIR | (B.tri_base + B.leaf_stride * (unsigned)(B.first + ca));
+        } else if (cb - ca <= B.group) { // a group of triangles behind one box, neighbours in the pool
+            for (int k = 0; k < 3; k++) { cl[c][k] = 1e300; ch[c][k] = -1e300; }
+            for (int i = ca; i < cb; i++)
+                for (int k = 0; k < 3; k++) { cl[c][k] = std::min(cl[c][k], bt[i].lo[k]); ch[c][k] = std::max(ch[c][k], bt[i].hi[k]); }
+            q.item[c] = IT_GROUP | ((unsigned)(cb - ca - 2) << 26) | (unsigned)(B.first + ca);
         } else {
             const size_t me = B.out->size();
             B.out->emplace_back();
@@ -1844,7 +1871,7 @@ void kid_fill(KidRec &kr, const double lo[3][3], const double hi[3][3], const bo
 
 // fills the list record of a list longer than SMALL_LIST and permutes order[first..first+count)
 void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &order, std::vector<QuadRec> &cull, unsigned cull_base,
-                unsigned tri_base, QuadRec &li, ListHdr &hdr, int &max_depth, double g0, double lbox_lo[3], double lbox_hi[3]) {
+                unsigned tri_base, QuadRec &li, ListHdr &hdr, int &max_depth, double g0, double lbox_lo[3], double lbox_hi[3], int group) {
     std::vector<CullTri> bt((size_t)count);
     std::vector<double> kt((size_t)count); // margin coefficient 2 * (1e-9 L^2 + 1e-10) of each triangle, L its longest edge
     double lmax2 = 0;
@@ -1882,6 +1909,7 @@ void build_list(const rt_scene_desc *D, int first, int count, std::vector<int> &
             for (int k = 0; k < 3; k++) { bt[j].lo[k] -= grow; bt[j].hi[k] += grow; }
         }
     CullBuild B = {&cull, &bt, cull_base, tri_base, first, 0};
+    B.group = group;
     cull_fill(B, 0, count, 1, li, lbox_lo, lbox_hi);
     max_depth = std::max(max_depth, B.max_depth);
     for (int j = 0; j < count; j++) order[first + j] = bt[j].src;
@@ -2211,6 +2239,13 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (dev < 0 || dev >= ndev) return fail(RT_E_INVALID, "device %d not in [0,%d)", dev, ndev);
     HIP_TRY(hipSetDevice(dev));
+    // which build of the kernel the scene runs: it also decides how the culling hierarchies are built (KernelCfg::group)
+    int deep_from = DEEP_TREE;
+    if (const char *e = getenv("RT_HIP_DEEP_TREE")) deep_from = atoi(e); // tuning / test knob: 0 = always the 8-level ring
+    const bool deep = tree_depth >= deep_from;
+    const int group = deep ? CFG_DEEP.group : CFG_SHALLOW.group;
+    static_assert(CFG_DEEP.group >= 2 && CFG_DEEP.group <= 4 && CFG_SHALLOW.group >= 2 && CFG_SHALLOW.group <= 4, "group items hold 2 to 4 triangles");
+    if (D->n_tris > (int)GROUP_POS) return fail(RT_E_LIMIT, "n_tris %d exceeds %u", D->n_tris, GROUP_POS);
 
     // pool layout in 16-byte granules: nodes (4 each), their list records (4 each), their child- and list-box records (3 each),
     // triangles (5), cull records (4); how many cull records the hierarchies take is only known once they are built
@@ -2270,7 +2305,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
                     double klo[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, khi[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
                     bool has[3] = {false, false, false};
                     if (cnt > SMALL_LIST) { // (disjoint ranges of `order` per list)
-                        build_list(D, first, cnt, order, lc, (unsigned)g_cull, (unsigned)g_tri, li, hdr, chunk_depth[(size_t)c], g0, klo[2], khi[2]);
+                        build_list(D, first, cnt, order, lc, (unsigned)g_cull, (unsigned)g_tri, li, hdr, chunk_depth[(size_t)c], g0, klo[2], khi[2], group);
                         has[2] = true;
                     } else {
                         hdr.meta = LIST_SHORT | (unsigned)cnt;
@@ -2469,9 +2504,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->cold.lights = (const int *)s->lights;
     s->cold.n_lights = (int)lights.size();
 
-    int deep_from = DEEP_TREE;
-    if (const char *e = getenv("RT_HIP_DEEP_TREE")) deep_from = atoi(e); // tuning / test knob: 0 = always the 8-level ring
-    s->deep = tree_depth >= deep_from;
+    s->deep = deep;
     const KernelCfg cfg = s->deep ? CFG_DEEP : CFG_SHALLOW;
     s->slots = cfg.slots;
     s->wpg = cfg.wpg;
@@ -2545,6 +2578,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     }
     s->d.padc = 2.5e-5 + 4e-12 * boxsum;
     s->d.g_list = (unsigned)g_list;
+    s->d.g_tri = (unsigned)g_tri;
     s->d.g_sph = (unsigned)g_sph;
     s->d.g_sphc = (unsigned)g_sphc;
     s->d.sph_root = sph_root;
