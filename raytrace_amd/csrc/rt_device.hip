@@ -151,7 +151,7 @@ struct __attribute__((aligned(16))) KidRec {
     unsigned char q[3][3][2];
     unsigned char pad2[2];
     unsigned meta;        // the own list's margin coefficients (ListHdr::meta)
-    unsigned spare;
+    unsigned direct;      // the own list as ONE triangle, chain or group item, if it is no longer than a group; else 0
 };
 static_assert(sizeof(KidRec) == 48, "KidRec is three granules");
 constexpr unsigned KID_NOKIDS = 1, KID_LIST = 2, KID_EMPTY = 4; // children's boxes unusable; list box usable; own list empty
@@ -864,13 +864,19 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     // (a far child that is only counted joins the frame's number instead, while that has room)
                     const LaneMask mCountOnly = mFar3 & ~mFlag & mRoom;
                     const LaneMask mWantMarker = (mFar0 | mFlag) & ~mCountOnly;
-                    st = lanes(~mListMissed | mHasNear) ? st & ~ST_FLAG : st;
+                    // A list that is one item, with no near subtree to wait for, needs no step of its own for "the near child
+                    // has returned": what that step would do -- count a far child that is certain to fail, put the other kind
+                    // on the stack, restore the flag and the count it has just saved -- is done here, and its triangles come next.
+                    const unsigned direct = k2.w;
+                    const LaneMask mGoDirect = __ballot(direct != 0) & ~mListMissed & ~mHasNear;
+                    const LaneMask mOwnFrame = ~mGoDirect;
+                    st = lanes((~mListMissed | mHasNear) & mOwnFrame) ? st & ~ST_FLAG : st;
                     st = lanes(mHasNear & mListMissed & mCountOnly) ? st + (1u << ST_NSH) : st;
-                    st = lanes(~mListMissed | (mHasNear & mWantMarker)) ? st & ~ST_N : st; // the item starts a frame of its own
-                    push_item = lanes(mHasNear & ~mListMissed) ? after : lanes(mHasNear & mWantMarker) ? marker : 0u;
-                    next = lanes(mHasNear) ? near : lanes(~mListMissed) ? after : lanes(mFar12) ? far_item : 0u;
+                    st = lanes((~mListMissed | (mHasNear & mWantMarker)) & mOwnFrame) ? st & ~ST_N : st; // the item starts a frame of its own
+                    push_item = lanes(mHasNear & ~mListMissed) ? after : lanes(mHasNear & mWantMarker) ? marker : lanes(mGoDirect & mFar12) ? far_item : 0u;
+                    next = lanes(mHasNear) ? near : lanes(mGoDirect) ? direct : lanes(~mListMissed) ? after : lanes(mFar12) ? far_item : 0u;
                     skipped = lanes((mNearL | mNearR) & ~mHasNear);
-                    skipped_far = lanes(mListMissed & ~mHasNear & mFar3);
+                    skipped_far = lanes((mListMissed | mGoDirect) & ~mHasNear & mFar3);
                     want_pop = lanes(mListMissed & ~mHasNear & ~mFar12);
                 }
             }
@@ -2323,6 +2329,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
                         kid_fill(kr, klo, khi, has);
                         if (cnt == 0) kr.flags |= KID_EMPTY;
                         kr.meta = hdr.meta;
+                        if (cnt >= 1 && cnt <= group) kr.direct = li.item[0]; // the whole list is one triangle item
                         memcpy(&pool[(g_kid + 3 * (size_t)i) * 16], &kr, 48);
                     }
                     memcpy(&pool[(size_t)i * 64], &n, 64);
