@@ -900,6 +900,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         } else if (pick == K_CULL) {
             RT_MARK("cull");
             bool boxes = false;
+            bool ev_one = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
                 const unsigned g = (cur & IT_AFTER) ? S.g_list + after_granule(cur) : (cur & IDX28);
                 const uint4 *p = (const uint4 *)(S.pool + (size_t)g * 16);
@@ -925,6 +926,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                              "v"(r2.z), "v"(r2.w), "v"(it.x), "v"(it.y), "v"(it.z), "v"(it.w), "v"(hdr.x), "v"(hdr.y));
                 if (SPH) asm volatile("" : : "v"(sph_best));
 #endif
+                ev_one = it.y == 0 && it.z == 0 && it.w == 0 && (it.x >> 30) != 0; // (diagnostics)
                 const bool lim_on = sph_boxes || ((st & ST_FLAG) != 0) || ((cur & IT_AFTER) && ((cur >> 30) & 1));
                 if (sph_boxes) best_lim = (float)sph_best;
                 boxes = true;
@@ -1034,6 +1036,8 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 }
             }
             RT_EV(5, run && (cur & IT_AFTER)); RT_EV(6, boxes); RT_EV(7, boxes && want_pop); RT_EV(8, run && !boxes);
+            RT_EV(18, boxes && want_pop && (cur & IT_AFTER)); // a list whose first record already meets nothing
+            RT_EV(19, run && (cur & IT_AFTER) && ev_one); // a list that is one triangle item, entered after a near subtree
             l_culls += boxes ? 1u : 0u;
         } else if (pick == K_TRI) {
             RT_MARK("tri");
@@ -2704,7 +2708,7 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
         static const char *en[N_EVENTS] = {"node: record fetched", "node: exact check_aabb code", "node: refill", "node: marker", "node: box not met",
                                            "cull: after item", "cull: boxes tested", "cull: no box met", "cull: short list / none", "tri: step",
                                            "tri: frame has a hit", "tail: push", "tail: push moves a level to HBM", "tail: pop", "tail: marker popped",
-                                           "tail: traversal ends", "node: goes on without a push", "tail: popped level is in HBM", "", ""};
+                                           "tail: traversal ends", "node: goes on without a push", "tail: popped level is in HBM", "cull: list's first record meets no box", "cull: list of one item after a near subtree"};
         const double iters = (double)h[ST_ITERS], rays = (double)h[ST_RAYS];
         for (int k = 0; k < N_EVENTS; k++)
             if (en[k][0])
