@@ -38,6 +38,8 @@
 // the floating-point Moller-Trumbore test can still accept a ray (see ray_margin_factor()); subtrees
 // whose inflated box the ray misses are skipped, the surviving triangles go through the unchanged
 // exact test, and ties are broken by the stored list rank.  Results are identical by construction.
+// The hierarchy's leaves are single triangles or groups of two (three in the build for deep trees)
+// neighbours behind one box, which one step tests: a step's fixed cost is what limits the kernel.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
