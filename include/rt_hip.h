@@ -169,6 +169,20 @@ int rt_upload_scene(int dev, const rt_scene_desc *desc, rt_scene **out);
 int rt_free_scene(rt_scene *s);
 
 /*
+ * rt_upload_scene in two steps, for hosts that drive several GPUs: copyToDevice (cuda.cu:91-176) ran once per MPI
+ * rank, each of which had flattened the tree for itself (travKdTree, cuda.cu:68-89).  rt_prepare_scene does all the
+ * host-side work of an upload -- validation, the device layout of nodes, own lists and their culling hierarchies,
+ * triangles, spheres, textures -- without touching a GPU; rt_upload_prepared copies that layout to one device and
+ * may be called for different devices from different threads at the same time (the prepared scene is only read).
+ * rt_upload_scene(dev, desc, out) is rt_prepare_scene + rt_upload_prepared + rt_free_prepared.  `desc` is only read
+ * during rt_prepare_scene.
+ */
+typedef struct rt_prepared rt_prepared; /* opaque, host memory only */
+int rt_prepare_scene(const rt_scene_desc *desc, rt_prepared **out);
+int rt_upload_prepared(int dev, const rt_prepared *prep, rt_scene **out);
+int rt_free_prepared(rt_prepared *prep);
+
+/*
  * replaces the per-pixel cuda_radiance() loop (cuda_raytrace.h:13, raytrace.cpp:186-192,
  * cuda.cu:412-427) for a whole tile: one kernel launch, synchronous, HOST output buffers.
  *   rgb_out     [rows*cols*3] linear colour after the per-sub-pixel clamp and *0.25 average,
@@ -197,15 +211,17 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_tile *til
                            const rt_params *p, double *d_rgb, int32_t *d_prim_id, void *stream);
 
 /*
- * The same work as rt_render_tiles_device for callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The
- * call allocates and frees nothing: the work counter, the tile tables and the per-pixel sub-pixel buffers that
+ * The same work as rt_render_tiles_device for callers that cannot allocate device memory: tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The call allocates and frees nothing
+ * and looks nothing up: the work counter, the tile tables and the per-pixel sub-pixel buffers that
  * rt_render_tiles_device keeps in (growing) allocations of the scene live in one fixed array in device memory
- * that each GPU holds from library load until the process ends (about 25 MiB), which bounds a call to
- * RT_NOALLOC_MAX_TILES tiles, RT_NOALLOC_MAX_PIXELS pixels and RT_NOALLOC_MAX_BLOCKS blocks of 8 x 8 pixels
- * (a ragged tile edge takes a block of its own); more is rejected with RT_E_LIMIT.  Results are identical to
- * rt_render_tiles_device's.  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU --
- * from any scene, on any stream -- race; order them on one stream or synchronise between them.
+ * that each GPU holds from library load until the process ends (about 25 MiB; rt_upload_scene resolves its address
+ * on the scene's device), which bounds a call to RT_NOALLOC_MAX_TILES tiles, RT_NOALLOC_MAX_PIXELS pixels and
+ * RT_NOALLOC_MAX_BLOCKS blocks of 8 x 8 pixels (a ragged tile edge takes a block of its own); more is rejected
+ * with RT_E_LIMIT.  Results are identical to rt_render_tiles_device's.  Every call on a GPU uses that GPU's one
+ * array: calls that overlap on one GPU -- from any scene, on any stream -- race; order them on one stream or
+ * synchronise between them.  The call records events on `stream` (for rt_get_stats and rt_last_kernel_ms), so it
+ * is not meant to be captured into a HIP graph.
  */
 #define RT_NOALLOC_MAX_TILES 64
 #define RT_NOALLOC_MAX_PIXELS (1 << 18)
@@ -217,8 +233,9 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
  * (or since upload); synchronises the last stream used, then clears the counters. */
 int rt_get_stats(rt_scene *s, rt_stats *stats);
 
-/* Milliseconds the last render kernel of this scene took on its stream (HIP events recorded
- * around the launch); synchronises on the closing event. */
+/* Milliseconds the render kernel queued LAST on this scene took on its stream (every set of per-launch state has
+ * its own pair of HIP events around its kernel, so a launch overlapping on another stream does not disturb the
+ * figure); synchronises on the closing event. */
 int rt_last_kernel_ms(rt_scene *s, float *ms);
 
 /*

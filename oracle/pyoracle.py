@@ -312,6 +312,9 @@ def ref_lib():
         R.ref_tree_dump.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _ip, _ip, _ip, _ip, _ip]
         R.ref_primary_ray.argtypes = [_dp, _dp, _dp]
         R.ref_vec_norm.argtypes = [_dp, _dp]
+        R.ref_readfile.argtypes = [C.c_void_p, C.c_char_p, C.c_double, _dp, _dp, _dp, _dp, C.c_int]
+        R.ref_obj_num_polys.argtypes = [C.c_void_p, C.c_int]
+        R.ref_obj_dump.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip]
         _ref = R
     return _ref
 
@@ -346,6 +349,29 @@ class RefScene:
                                              None if tc is None else _d(tc), None if vn is None else _d(vn), int(type_), _i(tt), _d(ts))
         return self.R.ref_add_object(self.h, _d(v), v.shape[0], _d(_c3(lig)), _d(_c3(col)),
                                      None if tc is None else _d(tc), None if vn is None else _d(vn), int(type_))
+
+    def readfile(self, path, times, loc, rot_deg, lig, col, type_):
+        """Object::readfile (object.cpp:9-286) on one more Object, prepared as raytrace.cpp:110-127 does.  `mtllib` names are
+        opened relative to the working directory, so the call runs inside the file's directory.  Returns what the reader
+        made of the file -- per Polygon: verts[n,9], col[n,3], lig[n,3], ts[n,6], nc[n,3], type[n], has_tex[n] -- or None
+        if readfile returned false."""
+        path = os.path.abspath(str(path))
+        cwd = os.getcwd()
+        os.chdir(os.path.dirname(path))
+        try:
+            no = self.R.ref_readfile(self.h, path.encode(), float(times), _d(_c3(loc)), _d(_c3(rot_deg)), _d(_c3(lig)), _d(_c3(col)), int(type_))
+        finally:
+            os.chdir(cwd)
+        if no < 0:
+            return None
+        n = self.R.ref_obj_num_polys(self.h, no)
+        self.offsets.append(self.offsets[-1] + n)
+        out = dict(verts=np.zeros((n, 9)), col=np.zeros((n, 3)), lig=np.zeros((n, 3)), ts=np.zeros((n, 6)), nc=np.zeros((n, 3)),
+                   type=np.zeros(n, np.int32), has_tex=np.zeros(n, np.int32))
+        if n:
+            self.R.ref_obj_dump(self.h, no, _d(out["verts"]), _d(out["col"]), _d(out["lig"]), _d(out["ts"]), _d(out["nc"]), _i(out["type"]),
+                                _i(out["has_tex"]))
+        return out
 
     def flatten_desc(self):
         """Address of the rt_scene_desc that integration/rt_binding.h builds from the reference's objects."""

@@ -13,9 +13,16 @@
 //     Polygon ctor (nc) / intersect / getn / GetImageData / getcol   (polygon.h:17-89)
 //     Sphere::intersect, sphere_intersect    (sphere.h:13-21, sphere.cpp:3-14)
 //     Point3D / Ray                          (point.h)
-// raytrace.cpp (radiance, main) is NOT part of this build: it needs mpi.h and OpenCV,
+//     Object::readfile -- the OBJ / MTL reader (object.cpp:9-286) with Matrix::Rx/Ry/Rz and
+//     Matrix * Point3D (matrix.h:24-52, matrix.cpp): object.cpp and matrix.cpp include no OpenCV
+//     header, only the declaration of loadImage, which is defined below as a function that ends
+//     the process -- it is reached only for a material with an image (map_Kd / map_Ks), which
+//     the OBJ files read through this shim do not have.
+// raytrace.cpp (radiance, main) and opencvlib.cpp are NOT part of this build: they need OpenCV,
 // which the image lacks.
 #include <vector>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "point.h"
 #include "polygon.h"
@@ -32,6 +39,12 @@ struct RefScene {
     KdTree *tree;
     RefScene() : tree(NULL) {}
 };
+
+// opencvlib.h's loadImage (opencvlib.cpp:11-30 needs OpenCV): images are outside what this build can pin.
+void loadImage(unsigned char *&, int &, int &, const char file[], double) {
+    fprintf(stderr, "ref_l3_harness: loadImage(%s) reached -- this build reads OBJ files without images only\n", file);
+    abort();
+}
 
 static Ray mkray(const double *r) { return Ray(Point3D(r[0], r[1], r[2]), Point3D(r[3], r[4], r[5])); }
 
@@ -95,6 +108,44 @@ int ref_add_object_tex(void *h, const double *verts, int ntri, const double *lig
         o.polys.push_back(Polygon(p, n, ts, o.lig, c, o.type, t ? &t->data[0] : NULL, t ? t->sizex : 0, t ? t->sizey : 0));
     }
     return (int)s->objs.size() - 1;
+}
+
+// raytrace.cpp:110-127: one more Object, its lig / col / type set BEFORE readfile, then the reference's own reader.
+// `mtllib` names are opened relative to the working directory (object.cpp:55).  Returns the object's index, -1 if
+// readfile returned false (the object is then removed again).
+int ref_readfile(void *h, const char *path, double times, const double *loc, const double *rot, const double *lig,
+                 const double *col, int type) {
+    RefScene *s = (RefScene *)h;
+    s->objs.push_back(Object());
+    Object &o = s->objs.back();
+    o.lig = Point3D(lig[0], lig[1], lig[2]);
+    o.col = Point3D(col[0], col[1], col[2]);
+    o.type = (RType)type;
+    if (!o.readfile(std::string(path), times, Point3D(loc[0], loc[1], loc[2]), Point3D(rot[0], rot[1], rot[2]))) {
+        s->objs.pop_back();
+        return -1;
+    }
+    return (int)s->objs.size() - 1;
+}
+
+int ref_obj_num_polys(void *h, int no) { return (int)((RefScene *)h)->objs[no].polys.size(); }
+
+// What readfile made of the file: per Polygon its points3d (9), col (3), lig (3), ts[0..2].xy (6), nc (3), type and
+// whether it has an image.
+void ref_obj_dump(void *h, int no, double *verts, double *cols, double *ligs, double *ts, double *nc, int *type, int *has_tex) {
+    const Object &o = ((RefScene *)h)->objs[no];
+    for (size_t i = 0; i < o.polys.size(); i++) {
+        const Polygon &p = o.polys[i];
+        for (int k = 0; k < 3; k++) {
+            verts[9 * i + 3 * k] = p.points3d[k].x; verts[9 * i + 3 * k + 1] = p.points3d[k].y; verts[9 * i + 3 * k + 2] = p.points3d[k].z;
+            ts[6 * i + 2 * k] = p.ts[k].x; ts[6 * i + 2 * k + 1] = p.ts[k].y;
+        }
+        cols[3 * i] = p.col.x; cols[3 * i + 1] = p.col.y; cols[3 * i + 2] = p.col.z;
+        ligs[3 * i] = p.lig.x; ligs[3 * i + 1] = p.lig.y; ligs[3 * i + 2] = p.lig.z;
+        nc[3 * i] = p.nc.x; nc[3 * i + 1] = p.nc.y; nc[3 * i + 2] = p.nc.z;
+        type[i] = (int)p.type;
+        has_tex[i] = p.tex != NULL;
+    }
 }
 
 void ref_poly_getcol(void *h, int no, int nv, double u, double v, double *out) {

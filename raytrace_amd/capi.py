@@ -66,7 +66,8 @@ HOST_SYMBOLS = ["rth_scene_new", "rth_scene_free", "rth_add_mesh", "rth_add_sphe
                 "rth_add_texture", "rth_load_texture_file", "rth_set_mesh_textures",
                 "rth_load_scene_file", "rth_load_scene_file_ex", "rth_build", "rth_desc", "rth_num_tris", "rth_num_spheres", "rth_tonemap",
                 "rth_write_bmp", "rth_last_error"]
-DEVICE_SYMBOLS = ["rt_device_count", "rt_device_info", "rt_upload_scene", "rt_free_scene", "rt_render_tile",
+DEVICE_SYMBOLS = ["rt_device_count", "rt_device_info", "rt_upload_scene", "rt_free_scene", "rt_prepare_scene", "rt_upload_prepared",
+                  "rt_free_prepared", "rt_render_tile",
                   "rt_render_tiles_device", "rt_render_tiles_noalloc", "rt_get_stats", "rt_last_kernel_ms", "rt_trace_rays", "rt_debug_fp64",
                   "rt_last_error"]
 
@@ -126,6 +127,9 @@ def device_lib():
         D.rt_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         D.rt_upload_scene.argtypes = [C.c_int, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         D.rt_free_scene.argtypes = [C.c_void_p]
+        D.rt_prepare_scene.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        D.rt_upload_prepared.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        D.rt_free_prepared.argtypes = [C.c_void_p]
         D.rt_render_tile.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Tile), C.POINTER(Params), _dp, _ip,
                                      C.POINTER(Stats)]
         D.rt_render_tiles_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Tile), C.c_int32, C.POINTER(Params),

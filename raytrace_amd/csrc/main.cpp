@@ -111,6 +111,9 @@ int main(int argc, char **argv) {
         for (const rt_tile &t : share[g]) counts[g] += (uint64_t)t.rows * t.cols * 3;
         total += counts[g];
     }
+    // the device layout (culling hierarchies and all) is built once, on the host, and uploaded by every GPU's thread
+    rt_prepared *prep = nullptr;
+    if (rt_prepare_scene(desc, &prep) < 0) { fprintf(stderr, "%s\n", rt_last_error()); return 1; }
     rt_gather *xg = nullptr;
     if (use_rccl) { // raytrace.cpp:99-104: the group of ranks
         std::vector<int32_t> devs((size_t)ndev);
@@ -128,7 +131,7 @@ int main(int argc, char **argv) {
             if (rt_device_info(g, info, sizeof(info)) == 0) printf("%s\n", info); // raytrace.cpp:164
             rt_scene *ds = nullptr;
             double *d_rgb = nullptr, *d_all = nullptr;
-            int rc = rt_upload_scene(g, desc, &ds);
+            int rc = rt_upload_prepared(g, prep, &ds);
             if (rc == 0 && hipMalloc((void **)&d_rgb, std::max<uint64_t>(counts[g], 1) * sizeof(double)) != hipSuccess) rc = RT_E_NOMEM;
             if (rc == 0 && use_rccl && g == 0 && hipMalloc((void **)&d_all, total * sizeof(double)) != hipSuccess) rc = RT_E_NOMEM;
             if (rc == 0 && !share[g].empty())
@@ -138,7 +141,16 @@ int main(int argc, char **argv) {
             const bool all_ok = meet.arrive(rc == 0);
             if (all_ok && use_rccl) { // raytrace.cpp:211, 219-227: every rank's share to rank 0
                 rc = rt_gather_shares(xg, g, d_rgb, d_all, counts.data(), nullptr);
-                if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = RT_E_DEVICE;
+                if (rc != 0) { status[g] = rc; errors[g] = rt_gather_last_error(); }
+                // A rank whose half of the exchange was never queued leaves the others waiting for it for ever:
+                // all meet again, and if any failed the process ends here, naming the rank, instead of hanging in
+                // a synchronisation on a collective that cannot complete.
+                if (!meet.arrive(rc == 0)) {
+                    if (rc != 0) fprintf(stderr, "GPU %d failed in the exchange: %s\n", g, errors[g].c_str());
+                    fflush(stderr);
+                    std::_Exit(1);
+                }
+                if (hipDeviceSynchronize() != hipSuccess) rc = RT_E_DEVICE;
                 if (rc == 0 && g == 0 && hipMemcpy(gathered.data(), d_all, total * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RT_E_DEVICE;
                 if (rc != 0) { status[g] = rc; errors[g] = rc == RT_E_DEVICE && !*rt_gather_last_error() ? "HIP error after the exchange" : rt_gather_last_error(); }
             } else if (all_ok) {
@@ -152,6 +164,7 @@ int main(int argc, char **argv) {
             rt_free_scene(ds);
         });
     for (auto &w : workers) w.join();
+    rt_free_prepared(prep);
     if (xg) rt_gather_destroy(xg);
     for (int g = 0; g < ndev; g++)
         if (status[g]) { fprintf(stderr, "GPU %d failed: %s\n", g, errors[g].c_str()); return 1; }

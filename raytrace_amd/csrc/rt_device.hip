@@ -49,6 +49,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -1542,6 +1543,21 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
 // copied from host memory and the write is ordered with the launches on the stream).
 __global__ void k_put_cold(ColdArgs a, ColdArgs *dst) { *dst = a; }
 
+// A launch's tile table and block-to-tile table are written by kernels as well (the tiles arrive as kernel arguments,
+// a chunk per launch): no host memory is read after the call returns, so a changed tile list never makes the host
+// wait for the copy of the previous one.
+constexpr int TILE_CHUNK = 96; // 3 KiB of kernel arguments
+struct TileChunk { DevTile t[TILE_CHUNK]; };
+__global__ void k_put_tiles(TileChunk c, int n, DevTile *dst) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = c.t[threadIdx.x];
+}
+// one workgroup per tile: the tile's 8x8 blocks all name it
+__global__ void k_fill_blk(const DevTile *tiles, int *blk) {
+    const DevTile t = tiles[blockIdx.x];
+    const int n = ((t.rows + 7) / 8) * t.blk_cols;
+    for (int b = (int)threadIdx.x; b < n; b += (int)blockDim.x) blk[t.blk_first + b] = (int)blockIdx.x;
+}
+
 __global__ void k_fp64(int op, long long n, const double *a, const double *b, double *out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1626,16 +1642,16 @@ struct LaunchCtx {
     long long blk_cap = 0;
     DevTile *d_tiles = nullptr;
     int tiles_cap = 0;
-    std::vector<DevTile> h_tiles;
-    std::vector<int> h_blk_tile;
+    std::vector<DevTile> h_tiles;         // the tile list the device tables were written from
     double *d_sub = nullptr;     // shares of the sub-pixels of the frame being rendered [pixel][4][3]
     unsigned *d_subcnt = nullptr; // finished sub-pixels per pixel
     size_t sub_cap = 0;          // pixels both hold
-    hipEvent_t ev_tables = nullptr;       // recorded behind the last upload of the tile tables
-    hipStream_t tables_stream = nullptr;  // the stream that upload was queued on
-    bool tables_valid = false;            // d_tiles / d_blk_tile hold what h_tiles / h_blk_tile say
-    bool tables_stream_set = false;       // an upload has been queued at all
+    hipEvent_t ev_tables = nullptr;       // recorded behind the kernels that last wrote the tile tables
+    hipStream_t tables_stream = nullptr;  // the stream they were queued on
+    bool tables_valid = false;            // d_tiles / d_blk_tile hold what h_tiles says
     hipEvent_t ev_done = nullptr;         // recorded behind the last launch that used this set
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // around that launch's render kernel, for rt_last_kernel_ms
+    bool timed = false;                   // ev0 / ev1 have been recorded
     hipStream_t stream = nullptr;         // the stream of that launch
     bool allocated = false, used = false;
     unsigned long long seq = 0;           // when it was last used
@@ -1657,10 +1673,28 @@ struct rt_scene {
     double *d_stage_rgb = nullptr; // rt_render_tile's device-side output buffers, kept between calls
     int *d_stage_prim = nullptr;
     size_t stage_cap = 0;        // pixels both hold
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    void *d_trace = nullptr;     // rt_trace_rays' device-side buffers (rays in, four result arrays out), kept between calls
+    size_t trace_cap = 0;        // rays they hold
+    unsigned char *scratch = nullptr; // this device's copy of the fixed array rt_render_tiles_noalloc works in
     bool deep = false;           // which build of the kernel this scene runs (KernelCfg)
     int slots = 0, wpg = 1;      // its slots per wavefront and wavefronts per workgroup
+};
+
+// A scene laid out for the device, in host memory: everything rt_upload_scene builds before it touches a GPU.  Built once,
+// uploaded to as many GPUs as there are (from as many threads).
+struct rt_prepared {
+    std::vector<char> pool;
+    std::vector<ListHdr> lhdr;
+    std::vector<TriShade> tsh;
+    std::vector<uint2> tls;
+    std::vector<SphGeom> sg;
+    std::vector<SphShade> ss;
+    std::vector<unsigned char> texblk;
+    std::vector<int> lights;
+    DevScene d{};    // the scene's constants (the device pointers are filled per upload)
+    ColdArgs cold{};
+    int tree_depth = 0, cull_depth = 0;
+    bool deep = false, has_tex = false;
 };
 
 using KernelFn = void (*)(DevScene, const ColdArgs *, unsigned long long *);
@@ -2086,6 +2120,8 @@ int alloc_ctx(rt_scene *s, LaunchCtx &c) {
     if (e == hipSuccess) e = hipMalloc((void **)&c.d_cold, sizeof(ColdArgs));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ev_tables, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&c.ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c.ev1);
     if (e != hipSuccess) return fail(RT_E_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
     c.allocated = true;
     return RT_OK;
@@ -2165,23 +2201,22 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
         c.tables_valid = false;
     }
     if (!c.tables_valid || c.h_tiles.size() != ht.size() || memcmp(c.h_tiles.data(), ht.data(), sizeof(DevTile) * ht.size()) != 0) {
-        c.tables_valid = false; // until both copies are queued
-        // the copies below read members of the set: the previous upload must have read them before they change
-        if (c.tables_stream_set) HIP_TRY(hipEventSynchronize(c.ev_tables));
-        c.h_tiles = ht;
-        c.h_blk_tile.resize((size_t)blocks);
-        for (int i = 0; i < n_tiles; i++) {
-            const long long end = i + 1 < n_tiles ? ht[i + 1].blk_first : blocks;
-            for (long long b = ht[i].blk_first; b < end; b++) c.h_blk_tile[(size_t)b] = i;
+        c.tables_valid = false; // until all the kernels are queued
+        // (this stream is already ordered behind the set's previous launch, the last reader of the old tables)
+        for (int first = 0; first < n_tiles; first += TILE_CHUNK) {
+            TileChunk ch;
+            const int n = std::min(TILE_CHUNK, n_tiles - first);
+            memcpy(ch.t, ht.data() + first, sizeof(DevTile) * (size_t)n);
+            hipLaunchKernelGGL(k_put_tiles, dim3(1), dim3(TILE_CHUNK), 0, stream, ch, n, c.d_tiles + first);
         }
-        HIP_TRY(hipMemcpyAsync(c.d_blk_tile, c.h_blk_tile.data(), sizeof(int) * (size_t)blocks, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(c.d_tiles, c.h_tiles.data(), sizeof(DevTile) * ht.size(), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_fill_blk, dim3(n_tiles), dim3(64), 0, stream, (const DevTile *)c.d_tiles, c.d_blk_tile);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev_tables, stream));
+        c.h_tiles = ht;
         c.tables_stream = stream;
-        c.tables_stream_set = true;
         c.tables_valid = true;
     } else if (stream != c.tables_stream) {
-        // the cached tables were uploaded on another stream: this launch must not start before they have landed
+        // the cached tables were written on another stream: this launch must not start before they have landed
         HIP_TRY(hipStreamWaitEvent(stream, c.ev_tables, 0));
     }
     if ((size_t)off > c.sub_cap) {
@@ -2198,7 +2233,6 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     int grid_cap = 0;
     const KernelFn kern = render_kernel(s, p, &grid_cap);
     const int grid = (int)std::min<long long>(grid_cap, (blocks * 256 + s->slots * s->wpg - 1) / (s->slots * s->wpg));
-    HIP_TRY(hipEventRecord(s->ev0, stream));
     ColdArgs ca = s->cold;
     ca.cam = dc; ca.P = *p;
     ca.tiles = c.d_tiles; ca.blk_tile = c.d_blk_tile; ca.counter = c.d_counter;
@@ -2208,11 +2242,12 @@ int launch_render(rt_scene *s, const rt_camera *cam, const rt_tile *tiles, int n
     HIP_TRY(hipGetLastError());
     DevScene dsc = s->d;
     dsc.ovf = (unsigned *)c.ovf; dsc.lstate = (double *)c.lstate;
+    HIP_TRY(hipEventRecord(c.ev0, stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, stream, dsc, (const ColdArgs *)c.d_cold, s->d_stats);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->ev1, stream));
+    HIP_TRY(hipEventRecord(c.ev1, stream));
     HIP_TRY(hipEventRecord(c.ev_done, stream));
-    s->timed = true;
+    c.timed = true;
     return RT_OK;
 }
 
@@ -2241,16 +2276,15 @@ int rt_device_info(int dev, char *buf, size_t cap) {
     return RT_OK;
 }
 
-int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
+int rt_prepare_scene(const rt_scene_desc *D, rt_prepared **out) {
     if (!out) return fail(RT_E_INVALID, "out is NULL");
     *out = nullptr;
     int tree_depth = 0; // the tree's real depth (a caller may state more, never less)
     int rc = validate(D, &tree_depth);
     if (rc) return rc;
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (dev < 0 || dev >= ndev) return fail(RT_E_INVALID, "device %d not in [0,%d)", dev, ndev);
-    HIP_TRY(hipSetDevice(dev));
+    std::unique_ptr<rt_prepared> P(new (std::nothrow) rt_prepared());
+    if (!P) return fail(RT_E_NOMEM, "out of host memory");
+    try {
     // which build of the kernel the scene runs: it also decides how the culling hierarchies are built (KernelCfg::group)
     int deep_from = DEEP_TREE;
     if (const char *e = getenv("RT_HIP_DEEP_TREE")) deep_from = atoi(e); // tuning / test knob: 0 = always the 8-level ring
@@ -2265,9 +2299,11 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
                  g_sph = g_tri + 5 * (size_t)D->n_tris, // copies of the spheres (2 granules each) for the sphere hierarchy's leaves
                  g_cull = (g_sph + 2 * (size_t)D->n_spheres + 6) & ~(size_t)3;
     if (g_cull + 4 > (size_t)IDX28) return fail(RT_E_LIMIT, "scene too large for the 28-bit record index");
-    std::vector<char> pool(g_cull * 16, 0);
+    std::vector<char> &pool = P->pool;
+    pool.assign(g_cull * 16, 0);
     std::vector<QuadRec> cull;
-    std::vector<ListHdr> lhdr((size_t)D->n_nodes);
+    std::vector<ListHdr> &lhdr = P->lhdr;
+    lhdr.assign((size_t)D->n_nodes, ListHdr{0u, 0u});
     // the ray margin factor up to which a list's working coefficient applies: four times the scene's reach
     // (summed half extents of the vertex box + longest edge), i.e. every origin within about three scene sizes
     double g0 = 1.0;
@@ -2426,12 +2462,14 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     for (int i = 0; i < D->n_nodes; i++)
         if (D->node_count[i] > 0) last[(size_t)D->node_first[i] + D->node_count[i] - 1] = 1;
     double blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0}, lg2 = 0; // vertex box and longest edge of the scene
-    std::vector<TriShade> tsh((size_t)D->n_tris);
+    std::vector<TriShade> &tsh = P->tsh;
+    tsh.resize((size_t)D->n_tris);
     std::vector<TexTri> textri;
     std::vector<unsigned> list_first((size_t)D->n_list, 0); // by list position: where its own list starts
     for (int i = 0; i < D->n_nodes; i++)
         for (int k = 0; k < D->node_count[i]; k++) list_first[(size_t)D->node_first[i] + k] = (unsigned)D->node_first[i];
-    std::vector<uint2> tls((size_t)D->n_list);
+    std::vector<uint2> &tls = P->tls;
+    tls.resize((size_t)D->n_list);
     for (int pos = 0; pos < D->n_list; pos++) {
         const int rank = order[pos];
         const int g = D->list_tri[rank];
@@ -2474,7 +2512,7 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         }
     }
     const size_t n_textri = textri.size();
-    std::vector<unsigned char> texblk;
+    std::vector<unsigned char> &texblk = P->texblk;
     if (n_textri) {
         std::vector<unsigned long long> img_off((size_t)D->n_textures);
         size_t at = TEX_OFF_TRI + n_textri * sizeof(TexTri);
@@ -2488,8 +2526,10 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         for (int k = 0; k < D->n_textures; k++)
             memcpy(texblk.data() + img_off[k], D->tex_data + D->tex_offset[k], 3 * (size_t)D->tex_sizex[k] * D->tex_sizey[k]);
     }
-    std::vector<SphGeom> sg((size_t)D->n_spheres);
-    std::vector<SphShade> ss((size_t)D->n_spheres);
+    std::vector<SphGeom> &sg = P->sg;
+    std::vector<SphShade> &ss = P->ss;
+    sg.resize((size_t)D->n_spheres);
+    ss.resize((size_t)D->n_spheres);
     for (int i = 0; i < D->n_spheres; i++) {
         sg[i].px = D->sph_pos[3 * i]; sg[i].py = D->sph_pos[3 * i + 1]; sg[i].pz = D->sph_pos[3 * i + 2];
         sg[i].rad = D->sph_rad[i];
@@ -2498,26 +2538,81 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
         ss[i].pad0 = 0; ss[i].pad1 = 0;
     }
 
+    for (int i = 0; i < D->n_spheres; i++) // the emissive spheres (rt_params.light_mode 1 samples them)
+        if (ss[i].lig[0] != 0 || ss[i].lig[1] != 0 || ss[i].lig[2] != 0) P->lights.push_back(i);
+    P->tree_depth = tree_depth;
+    P->cull_depth = cull_depth;
+    P->deep = deep;
+    P->has_tex = n_textri != 0;
+    P->cold.n_lights = (int)P->lights.size();
+    P->cold.reach = std::sqrt(lg2) * 1.000001;
+    P->cold.absn = 0;
+    for (int k = 0; k < 3; k++) {
+        P->cold.cen[k] = 0.5 * (blo[k] + bhi[k]);
+        P->cold.reach += 0.5 * (bhi[k] - blo[k]) * 1.000001;
+        P->cold.absn += std::fabs(P->cold.cen[k]) + 0.5 * (bhi[k] - blo[k]);
+    }
+    double boxsum = 0;
+    for (int i = 0; i < D->n_nodes; i++) {
+        double b = 0;
+        for (int k = 0; k < 6; k++) b += std::fabs(D->node_box[6 * (size_t)i + k]);
+        if (!(b <= boxsum)) boxsum = b; // also takes a NaN, which then disables the shortcut
+    }
+    P->d.padc = 2.5e-5 + 4e-12 * boxsum;
+    P->d.g_list = (unsigned)g_list;
+    P->d.g_tri = (unsigned)g_tri;
+    P->d.g_sph = (unsigned)g_sph;
+    P->d.g_sphc = (unsigned)g_sphc;
+    P->d.sph_root = sph_root;
+    P->d.sph_k = sph_k; P->d.sph_c = sph_c;
+    for (int k = 0; k < 3; k++) P->d.sph_cen[k] = sph_cen[k];
+    P->d.sph_h = sph_h;
+    P->d.fslack = f_up(16.0 * 5.97e-8 * (P->cold.absn + P->cold.reach)); // see the cull step
+    P->d.n_sph = D->n_spheres;
+    } catch (const std::bad_alloc &) {
+        return fail(RT_E_NOMEM, "out of host memory while laying the scene out");
+    }
+    *out = P.release();
+    return RT_OK;
+}
+
+int rt_free_prepared(rt_prepared *p) {
+    delete p;
+    return RT_OK;
+}
+
+int rt_upload_prepared(int dev, const rt_prepared *P, rt_scene **out) {
+    if (!out) return fail(RT_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!P) return fail(RT_E_INVALID, "prepared scene is NULL");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (dev < 0 || dev >= ndev) return fail(RT_E_INVALID, "device %d not in [0,%d)", dev, ndev);
+    HIP_TRY(hipSetDevice(dev));
+    const int tree_depth = P->tree_depth, cull_depth = P->cull_depth;
+    const unsigned sph_root = P->d.sph_root;
+    const bool has_tex = P->has_tex;
+    int rc = RT_OK;
     rt_scene *s = new (std::nothrow) rt_scene();
     if (!s) return fail(RT_E_NOMEM, "out of host memory");
     s->dev = dev;
     s->tree_depth = tree_depth;
-    rc = upload(&s->pool, pool);
-    if (!rc) rc = upload(&s->lhdr, lhdr);
-    if (!rc) rc = upload(&s->tshade, tsh);
-    if (!rc) rc = upload(&s->tlist, tls);
-    if (!rc) rc = upload(&s->sph, sg);
-    if (!rc) rc = upload(&s->sshade, ss);
-    if (!rc && n_textri) rc = upload(&s->tex, texblk);
-    std::vector<int> lights; // the emissive spheres (rt_params.light_mode 1 samples them)
-    for (int i = 0; i < D->n_spheres; i++)
-        if (ss[i].lig[0] != 0 || ss[i].lig[1] != 0 || ss[i].lig[2] != 0) lights.push_back(i);
-    if (!rc && !lights.empty()) rc = upload(&s->lights, lights);
+    rc = upload(&s->pool, P->pool);
+    if (!rc) rc = upload(&s->lhdr, P->lhdr);
+    if (!rc) rc = upload(&s->tshade, P->tsh);
+    if (!rc) rc = upload(&s->tlist, P->tls);
+    if (!rc) rc = upload(&s->sph, P->sg);
+    if (!rc) rc = upload(&s->sshade, P->ss);
+    if (!rc && has_tex) rc = upload(&s->tex, P->texblk);
+    if (!rc && !P->lights.empty()) rc = upload(&s->lights, P->lights);
+    // this device's copy of the array rt_render_tiles_noalloc works in: resolved here, once, so that entry point looks nothing up
+    if (!rc) rc = scratch_address(dev, &s->scratch);
     if (rc) { rt_free_scene(s); return rc; }
+    s->d = P->d;       // the scene's constants; the pointers follow
+    s->cold = P->cold;
     s->cold.lights = (const int *)s->lights;
-    s->cold.n_lights = (int)lights.size();
 
-    s->deep = deep;
+    s->deep = P->deep;
     const KernelCfg cfg = s->deep ? CFG_DEEP : CFG_SHALLOW;
     s->slots = cfg.slots;
     s->wpg = cfg.wpg;
@@ -2534,11 +2629,11 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     // (the instances this scene can run -- render, explicit rays, render with light sampling -- each get the grid that fills the chip at
     // their own occupancy; the per-slot state arrays are sized for the larger one)
     int per_cu = 0, per_cu_t = 0, per_cu_l = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel<false>(sph_root != 0, s->deep, n_textri != 0), WAVE * cfg.wpg, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel<false>(sph_root != 0, s->deep, has_tex), WAVE * cfg.wpg, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, pick_kernel<true>(sph_root != 0, s->deep, false), WAVE * cfg.wpg, 0) != hipSuccess || per_cu_t < 1)
         per_cu_t = 4;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, pick_kernel<false>(sph_root != 0, s->deep, n_textri != 0, true), WAVE * cfg.wpg, 0) != hipSuccess || per_cu_l < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, pick_kernel<false>(sph_root != 0, s->deep, has_tex, true), WAVE * cfg.wpg, 0) != hipSuccess || per_cu_l < 1)
         per_cu_l = 4;
     s->grid = pr.multiProcessorCount * per_cu;
     s->grid_trace = pr.multiProcessorCount * per_cu_t;
@@ -2563,8 +2658,6 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     }
     hipError_t e = hipMalloc((void **)&s->d_stats, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipEventCreate(&s->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&s->ev1);
     if (e != hipSuccess) {
         rt_free_scene(s);
         return fail(RT_E_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
@@ -2574,43 +2667,30 @@ int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
     s->d.tlist = (const uint2 *)s->tlist;
     s->cold.sph = (const SphGeom *)s->sph;
     s->cold.sshade = (const SphShade *)s->sshade;
-    s->cold.tex = n_textri ? (const unsigned char *)s->tex : nullptr;
+    s->cold.tex = has_tex ? (const unsigned char *)s->tex : nullptr;
     s->d.ovf = nullptr; s->d.lstate = nullptr; // per launch
-    s->cold.reach = std::sqrt(lg2) * 1.000001;
-    s->cold.absn = 0;
-    for (int k = 0; k < 3; k++) {
-        s->cold.cen[k] = 0.5 * (blo[k] + bhi[k]);
-        s->cold.reach += 0.5 * (bhi[k] - blo[k]) * 1.000001;
-        s->cold.absn += std::fabs(s->cold.cen[k]) + 0.5 * (bhi[k] - blo[k]);
-    }
-    double boxsum = 0;
-    for (int i = 0; i < D->n_nodes; i++) {
-        double b = 0;
-        for (int k = 0; k < 6; k++) b += std::fabs(D->node_box[6 * (size_t)i + k]);
-        if (!(b <= boxsum)) boxsum = b; // also takes a NaN, which then disables the shortcut
-    }
-    s->d.padc = 2.5e-5 + 4e-12 * boxsum;
-    s->d.g_list = (unsigned)g_list;
-    s->d.g_tri = (unsigned)g_tri;
-    s->d.g_sph = (unsigned)g_sph;
-    s->d.g_sphc = (unsigned)g_sphc;
-    s->d.sph_root = sph_root;
-    s->d.sph_k = sph_k; s->d.sph_c = sph_c;
-    for (int k = 0; k < 3; k++) s->d.sph_cen[k] = sph_cen[k];
-    s->d.sph_h = sph_h;
     s->d.lhdr = (const ListHdr *)s->lhdr;
-    s->d.fslack = f_up(16.0 * 5.97e-8 * (s->cold.absn + s->cold.reach)); // see the cull step
-    s->d.n_sph = D->n_spheres;
     s->d.ovf_depth = ovf_depth;
     s->d.n_slots = n_slots;
     *out = s;
     return RT_OK;
 }
 
+int rt_upload_scene(int dev, const rt_scene_desc *D, rt_scene **out) {
+    if (!out) return fail(RT_E_INVALID, "out is NULL");
+    *out = nullptr;
+    rt_prepared *P = nullptr;
+    int rc = rt_prepare_scene(D, &P);
+    if (rc) return rc;
+    rc = rt_upload_prepared(dev, P, out);
+    rt_free_prepared(P);
+    return rc;
+}
+
 int rt_free_scene(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->dev);
-    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->lights, s->lhdr, s->d_stats, s->d_stage_rgb, s->d_stage_prim};
+    void *ptrs[] = {s->pool, s->tshade, s->tlist, s->sph, s->sshade, s->tex, s->lights, s->lhdr, s->d_stats, s->d_stage_rgb, s->d_stage_prim, s->d_trace};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (LaunchCtx &c : s->ctx) {
@@ -2619,9 +2699,9 @@ int rt_free_scene(rt_scene *s) {
             if (p) (void)hipFree(p);
         if (c.ev_tables) (void)hipEventDestroy(c.ev_tables);
         if (c.ev_done) (void)hipEventDestroy(c.ev_done);
+        if (c.ev0) (void)hipEventDestroy(c.ev0);
+        if (c.ev1) (void)hipEventDestroy(c.ev1);
     }
-    if (s->ev0) (void)hipEventDestroy(s->ev0);
-    if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
     return RT_OK;
 }
@@ -2660,9 +2740,7 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
     }
     for (int i = n_tiles; i < (int)NA_MAX_TILES; i++) T.t[i] = rt_tile{0, 0, 0, 0};
     HIP_TRY(hipSetDevice(s->dev));
-    unsigned char *scr = nullptr;
-    rc = scratch_address(s->dev, &scr);
-    if (rc) return rc;
+    unsigned char *const scr = s->scratch; // looked up by rt_upload_scene: nothing is resolved here
     hipStream_t stream = (hipStream_t)stream_;
     LaunchCtx *cp = nullptr; // the rays' per-slot state is the first set's, which rt_upload_scene allocated
     rc = acquire_ctx(s, stream, true, &cp);
@@ -2676,7 +2754,6 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
     int grid_cap = 0;
     const KernelFn kern = render_kernel(s, p, &grid_cap);
     const int grid = (int)std::min<long long>(grid_cap, (blocks * 256 + s->slots * s->wpg - 1) / (s->slots * s->wpg));
-    HIP_TRY(hipEventRecord(s->ev0, stream));
     ColdArgs ca = s->cold;
     ca.cam = dc; ca.P = *p;
     ca.tiles = (const DevTile *)(scr + NA_OFF_TILES); ca.blk_tile = (const int *)(scr + NA_OFF_BLK); ca.counter = (unsigned *)(scr + NA_OFF_COUNTER);
@@ -2686,11 +2763,12 @@ int rt_render_tiles_noalloc(rt_scene *s, const rt_camera *cam, const rt_tile *ti
     HIP_TRY(hipGetLastError());
     DevScene dsc = s->d;
     dsc.ovf = (unsigned *)cp->ovf; dsc.lstate = (double *)cp->lstate;
+    HIP_TRY(hipEventRecord(cp->ev0, stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * s->wpg), 0, stream, dsc, (const ColdArgs *)(scr + NA_OFF_COLD), s->d_stats);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->ev1, stream));
+    HIP_TRY(hipEventRecord(cp->ev1, stream));
     HIP_TRY(hipEventRecord(cp->ev_done, stream));
-    s->timed = true;
+    cp->timed = true;
     return RT_OK;
 }
 
@@ -2738,10 +2816,13 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
 
 int rt_last_kernel_ms(rt_scene *s, float *ms) {
     if (!s || !ms) return fail(RT_E_INVALID, "NULL argument");
-    if (!s->timed) return fail(RT_E_INVALID, "no render has been launched on this scene");
+    const LaunchCtx *last = nullptr; // the set of the launch queued last: every set has its own pair of events
+    for (const LaunchCtx &c : s->ctx)
+        if (c.timed && (!last || c.seq > last->seq)) last = &c;
+    if (!last) return fail(RT_E_INVALID, "no render has been launched on this scene");
     HIP_TRY(hipSetDevice(s->dev));
-    HIP_TRY(hipEventSynchronize(s->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    HIP_TRY(hipEventSynchronize(last->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, last->ev0, last->ev1));
     return RT_OK;
 }
 
@@ -2787,17 +2868,20 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
         if (stats) memset(stats, 0, sizeof(*stats));
         return RT_OK;
     }
-    double *d_rays = nullptr, *d_tt = nullptr, *d_st = nullptr;
-    int *d_ti = nullptr, *d_si = nullptr;
     LaunchCtx *cp = nullptr;
     const int rc = acquire_ctx(s, nullptr, true, &cp);
     if (rc) return rc;
-    hipError_t e = hipMalloc((void **)&d_rays, (size_t)n * 6 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_tt, (size_t)n * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_st, (size_t)n * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_ti, (size_t)n * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_si, (size_t)n * sizeof(int));
-    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice);
+    // one allocation holds the rays and the four result arrays; it grows to the largest query seen and stays until rt_free_scene
+    constexpr size_t PER_RAY = 6 * sizeof(double) + 2 * sizeof(double) + 2 * sizeof(int);
+    if ((size_t)n > s->trace_cap) {
+        if (s->d_trace) (void)hipFree(s->d_trace);
+        s->d_trace = nullptr; s->trace_cap = 0;
+        HIP_TRY(hipMalloc(&s->d_trace, (size_t)n * PER_RAY));
+        s->trace_cap = (size_t)n;
+    }
+    double *const d_rays = (double *)s->d_trace, *const d_tt = d_rays + 6 * (size_t)n, *const d_st = d_tt + (size_t)n;
+    int *const d_ti = (int *)(d_st + (size_t)n), *const d_si = d_ti + (size_t)n;
+    hipError_t e = hipMemcpy(d_rays, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, N_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(cp->d_counter, 0, 16);
     if (e == hipSuccess) {
@@ -2820,7 +2904,6 @@ int rt_trace_rays(rt_scene *s, int64_t n, const double *rays, int32_t *tri_id, d
     if (e == hipSuccess) e = hipMemcpy(tri_t, d_tt, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(sph_id, d_si, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(sph_t, d_st, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(d_rays); (void)hipFree(d_tt); (void)hipFree(d_st); (void)hipFree(d_ti); (void)hipFree(d_si);
     if (e != hipSuccess) return fail(RT_E_DEVICE, "rt_trace_rays: %s", hipGetErrorString(e));
     rt_stats own;
     return rt_get_stats(s, stats ? stats : &own);

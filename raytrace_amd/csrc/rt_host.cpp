@@ -19,6 +19,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -190,10 +191,12 @@ int rth_add_mesh(rth_scene *s, const double *verts, int64_t n_tris, const double
 int rth_add_texture(rth_scene *s, const uint8_t *bgr, int32_t rows, int32_t cols) {
     if (!s || !bgr || rows < 1 || cols < 1) return fail(RT_E_INVALID, "rth_add_texture: bad arguments");
     if ((int64_t)rows * cols > (int64_t)1 << 28) return fail(RT_E_LIMIT, "rth_add_texture: image of %d x %d pixels is too large", rows, cols);
-    s->tex_offset.push_back((int64_t)s->tex_data.size());
+    const size_t before = s->tex_data.size();
+    try { s->tex_data.insert(s->tex_data.end(), bgr, bgr + 3 * (size_t)rows * cols); }
+    catch (const std::exception &) { return fail(RT_E_NOMEM, "rth_add_texture: out of memory"); }
+    s->tex_offset.push_back((int64_t)before);
     s->tex_sizex.push_back(cols);
     s->tex_sizey.push_back(rows);
-    s->tex_data.insert(s->tex_data.end(), bgr, bgr + 3 * (size_t)rows * cols);
     if (s->built) refresh_desc(s); // images are not part of the tree
     return (int)s->tex_offset.size() - 1;
 }
@@ -215,9 +218,13 @@ int rth_set_mesh_textures(rth_scene *s, int mesh, const int32_t *tri_tex, const 
 namespace {
 
 // An image file as rows x cols BGR bytes, top row first (what cv::imread returns for a colour image).
-bool read_image(const char *path, std::vector<uint8_t> &bgr, int &rows, int &cols) {
+// IMG_NOFILE: the file cannot be opened (the reference then leaves the material untextured, opencvlib.cpp:13-14);
+// IMG_FORMAT: it exists but is not one of the formats read here; IMG_LIMIT: its header states a size beyond the limits.
+enum { IMG_OK = 0, IMG_NOFILE = 1, IMG_FORMAT = 2, IMG_LIMIT = 3 };
+constexpr int64_t IMG_MAX_SIDE = 65536, IMG_MAX_PIXELS = (int64_t)1 << 28; // (rth_add_texture's own limit)
+int read_image_checked(const char *path, std::vector<uint8_t> &bgr, int &rows, int &cols) {
     FILE *f = fopen(path, "rb");
-    if (!f) return false;
+    if (!f) return IMG_NOFILE;
     std::vector<uint8_t> raw;
     uint8_t chunk[65536];
     size_t n;
@@ -229,10 +236,13 @@ bool read_image(const char *path, std::vector<uint8_t> &bgr, int &rows, int &col
         const int32_t w = (int32_t)le32(18), h = (int32_t)le32(22);
         const int bpp = raw[28] | (raw[29] << 8);
         const uint32_t comp = le32(30);
-        if (hdr < 40 || w < 1 || h == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && !(comp == 3 && bpp == 32))) return false;
-        const int ah = h < 0 ? -h : h;
+        if (hdr < 40 || w < 1 || h == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && !(comp == 3 && bpp == 32))) return IMG_FORMAT;
+        // the header is not trusted: sizes are bounded before anything is computed from them
+        const int64_t ah64 = h < 0 ? -(int64_t)h : (int64_t)h;
+        if (w > IMG_MAX_SIDE || ah64 > IMG_MAX_SIDE || (int64_t)w * ah64 > IMG_MAX_PIXELS) return IMG_LIMIT;
+        const int ah = (int)ah64;
         const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
-        if ((size_t)off + stride * ah > raw.size()) return false;
+        if ((size_t)off + stride * ah > raw.size()) return IMG_FORMAT;
         rows = ah; cols = w;
         bgr.resize(3 * (size_t)rows * cols);
         for (int r = 0; r < rows; r++) {
@@ -240,7 +250,7 @@ bool read_image(const char *path, std::vector<uint8_t> &bgr, int &rows, int &col
             for (int c = 0; c < cols; c++)
                 for (int k = 0; k < 3; k++) bgr[3 * ((size_t)r * cols + c) + k] = src[(size_t)c * (bpp / 8) + k];
         }
-        return true;
+        return IMG_OK;
     }
     if (raw.size() >= 11 && raw[0] == 'P' && raw[1] == '6') { // binary PPM: RGB bytes
         size_t p = 2;
@@ -253,18 +263,25 @@ bool read_image(const char *path, std::vector<uint8_t> &bgr, int &rows, int &col
             }
             long x = 0;
             bool any = false;
-            while (p < raw.size() && raw[p] >= '0' && raw[p] <= '9') { x = x * 10 + (raw[p] - '0'); p++; any = true; if (x > 1 << 28) return false; }
-            if (!any) return false;
+            while (p < raw.size() && raw[p] >= '0' && raw[p] <= '9') { x = x * 10 + (raw[p] - '0'); p++; any = true; if (x > 1 << 28) return IMG_LIMIT; }
+            if (!any) return IMG_FORMAT;
             v[k] = x;
         }
         p++; // the single white-space byte after maxval
-        if (v[0] < 1 || v[1] < 1 || v[2] < 1 || v[2] > 255 || p + 3 * (size_t)v[0] * (size_t)v[1] > raw.size()) return false;
+        if (v[0] < 1 || v[1] < 1 || v[2] < 1 || v[2] > 255) return IMG_FORMAT;
+        if (v[0] > IMG_MAX_SIDE || v[1] > IMG_MAX_SIDE || (int64_t)v[0] * v[1] > IMG_MAX_PIXELS) return IMG_LIMIT;
+        if (p + 3 * (size_t)v[0] * (size_t)v[1] > raw.size()) return IMG_FORMAT;
         cols = (int)v[0]; rows = (int)v[1];
         bgr.resize(3 * (size_t)rows * cols);
         for (size_t i = 0; i < (size_t)rows * cols; i++) { bgr[3 * i] = raw[p + 3 * i + 2]; bgr[3 * i + 1] = raw[p + 3 * i + 1]; bgr[3 * i + 2] = raw[p + 3 * i]; }
-        return true;
+        return IMG_OK;
     }
-    return false;
+    return IMG_FORMAT;
+}
+// (allocation failures stay inside: nothing is thrown through the C boundary)
+int read_image(const char *path, std::vector<uint8_t> &bgr, int &rows, int &cols) {
+    try { return read_image_checked(path, bgr, rows, cols); }
+    catch (const std::exception &) { return IMG_LIMIT; }
 }
 
 // cv::resize(src, dst, Size(dc, dr)) with its default bilinear interpolation for 8-bit images, as OpenCV publishes
@@ -316,15 +333,35 @@ void resize_bilinear(const std::vector<uint8_t> &src, int sr, int sc, std::vecto
 
 extern "C" {
 
-int rth_load_texture_file(rth_scene *s, const char *path, double times) {
-    if (!s || !path) return fail(RT_E_INVALID, "rth_load_texture_file: bad arguments");
+} // extern "C"
+
+namespace {
+// rth_load_texture_file; *missing says whether the failure is "the file cannot be opened"
+int load_texture(rth_scene *s, const char *path, double times, bool *missing) {
+    *missing = false;
     std::vector<uint8_t> img, out;
     int rows = 0, cols = 0;
-    if (!read_image(path, img, rows, cols)) return fail(RT_E_INVALID, "Can't read image %s (24/32-bit BMP or binary PPM expected)", path);
-    const int dc = (int)(cols * times), dr = (int)(rows * times); // opencvlib.cpp:16
-    if (dc < 1 || dr < 1) return fail(RT_E_INVALID, "%s: scaled to %d x %d pixels", path, dr, dc);
-    resize_bilinear(img, rows, cols, out, dr, dc);
+    const int st = read_image(path, img, rows, cols);
+    if (st == IMG_NOFILE) { *missing = true; return fail(RT_E_INVALID, "Can't open image %s", path); }
+    if (st == IMG_LIMIT) return fail(RT_E_LIMIT, "image %s: more than %lld pixels a side or %lld in all", path, (long long)IMG_MAX_SIDE, (long long)IMG_MAX_PIXELS);
+    if (st != IMG_OK) return fail(RT_E_INVALID, "Can't decode image %s: only uncompressed 24/32-bit BMP and binary PPM (P6) are read", path);
+    const double fc = cols * times, fr = rows * times; // opencvlib.cpp:16
+    if (!(fc >= 1) || !(fr >= 1)) return fail(RT_E_INVALID, "%s: scaled to %d x %d pixels", path, (int)fr, (int)fc);
+    if (fc > (double)IMG_MAX_SIDE || fr > (double)IMG_MAX_SIDE || fc * fr > (double)IMG_MAX_PIXELS)
+        return fail(RT_E_LIMIT, "image %s scaled by %g exceeds %lld pixels", path, times, (long long)IMG_MAX_PIXELS);
+    const int dc = (int)fc, dr = (int)fr;
+    try { resize_bilinear(img, rows, cols, out, dr, dc); }
+    catch (const std::exception &) { return fail(RT_E_NOMEM, "image %s: out of memory", path); }
     return rth_add_texture(s, out.data(), dr, dc);
+}
+} // namespace
+
+extern "C" {
+
+int rth_load_texture_file(rth_scene *s, const char *path, double times) {
+    if (!s || !path) return fail(RT_E_INVALID, "rth_load_texture_file: bad arguments");
+    bool missing = false;
+    return load_texture(s, path, times, &missing);
 }
 
 int rth_add_sphere(rth_scene *s, double rad, const double *pos, const double *lig, const double *col, int type) {
@@ -493,8 +530,12 @@ int rth_add_obj_file_ex(rth_scene *s, const char *path, double scale, const doub
                     if (!fgets(buf, sizeof(buf), fm)) break;
                     str[0] = 0;
                     sscanf(buf, "%511s", str);
-                    int img = rth_load_texture_file(s, (dir + str).c_str(), scale);
-                    if (img < 0) img = rth_load_texture_file(s, str, scale);
+                    // (a file that exists but cannot be decoded here -- PNG, JPEG, 8-bit BMP, which cv::imread reads -- is an
+                    // error that names the file: rendering it with the flat colour would silently differ from the reference)
+                    bool missing = false;
+                    int img = load_texture(s, (dir + str).c_str(), scale, &missing);
+                    if (img < 0 && missing) img = load_texture(s, str, scale, &missing);
+                    if (img < 0 && !missing) { rc = img; break; }
                     tex.back() = img < 0 ? -1 : img;
                 } else if (!fgets(buf, sizeof(buf), fm)) break;
             }

@@ -156,9 +156,9 @@ class FramePipeline:
         st = self.streams[slot]
         return self.torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
 
-    def submit(self, seed=None, kernel_events=None):
+    def submit(self, seed=None, kernel_events=None, assemble_events=None):
         """Queue the next frame (asynchronous) and return its slot.  kernel_events: a pair of torch events to record
-        around the kernel, on the stream it runs on."""
+        around the kernel, on the stream it runs on; assemble_events: likewise around the gather and the un-permute."""
         slot = self.submitted % self.depth
         self.submitted += 1
         fr = self.renderers[slot]
@@ -170,7 +170,11 @@ class FramePipeline:
             fr.launch()
             if kernel_events is not None:
                 kernel_events[1].record()
+            if assemble_events is not None:
+                assemble_events[0].record()
             fr.assemble()
+            if assemble_events is not None:
+                assemble_events[1].record()
         return slot
 
     def frame(self, slot):

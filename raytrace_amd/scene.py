@@ -149,14 +149,38 @@ def device_info(dev=0):
     return buf.value.decode()
 
 
+class PreparedScene:
+    """A scene laid out for the device in host memory (rt_prepare_scene): built once, uploaded to every GPU of the
+    process.  No GPU is touched."""
+
+    def __init__(self, host_scene):
+        self.D = capi.device_lib()
+        self.h = C.c_void_p()
+        check_dev(self.D.rt_prepare_scene(host_scene.desc, C.byref(self.h)), "rt_prepare_scene")
+
+    def close(self):
+        if self.h:
+            self.D.rt_free_prepared(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceScene:
-    """A scene resident in one GPU's HBM (rt_upload_scene)."""
+    """A scene resident in one GPU's HBM (rt_upload_scene, or rt_upload_prepared for a PreparedScene)."""
 
     def __init__(self, host_scene, dev=0):
         self.D = capi.device_lib()
         self.h = C.c_void_p()
         self.dev = dev
-        check_dev(self.D.rt_upload_scene(int(dev), host_scene.desc, C.byref(self.h)), "rt_upload_scene")
+        if isinstance(host_scene, PreparedScene):
+            check_dev(self.D.rt_upload_prepared(int(dev), host_scene.h, C.byref(self.h)), "rt_upload_prepared")
+        else:
+            check_dev(self.D.rt_upload_scene(int(dev), host_scene.desc, C.byref(self.h)), "rt_upload_scene")
 
     def close(self):
         if self.h:

@@ -14,6 +14,8 @@ Each .npz holds inputs (scene arrays, rays, points) and the reference's outputs 
     aabb_*      KdTreeNode::check_aabb for explicit (box, ray) pairs
     primary_*   Ray(cam.o + d * 140, d.norm()) as g++ evaluates it (raytrace.cpp:203)
     getcol_*    Polygon::getcol(u, v) of textured and plain triangles (polygon.h:73-89), images included as data
+    objload     Object::readfile (object.cpp:9-286): an OBJ + MTL pair written by this script (kept as bytes) read with
+                several scale / rotation / translation / material-type settings -> per Polygon points3d, col, lig, ts, nc
 Nothing of the reference's source text is stored, only numbers.
 """
 import os
@@ -171,6 +173,63 @@ def make_primary():
     print("primary", len(out))
 
 
+def objload_files(seed=3):
+    """An OBJ + MTL pair of this script's own making: comments, v / vn / vt lines, all four face forms the reference
+    accepts with normals present (v//n, v/t/n; plain v and v/t faces index vn[-1] there, undefined behaviour), a face
+    with a fourth vertex (dropped, object.cpp:186-257), groups, materials with Ka / Kd / Ks / Ns, a material named
+    twice (the last one wins, object.cpp:48), an unknown material (slot 0 = the object's colour); no images."""
+    rs = np.random.RandomState(seed)
+    nv, nn, nt = 40, 17, 23
+    v, vn, vt = rs.uniform(-3, 3, (nv, 3)), rs.normal(size=(nn, 3)), rs.uniform(0, 1, (nt, 2))
+    f3 = lambda x: " ".join(repr(float(a)) for a in x)  # noqa: E731
+    mtl = ("# materials\nnewmtl red\nKa 1 1 1\nKd 0.9 0.1 0.2\nKs 0.3 0.4 0.5\nNs 10\nd 1\n\nnewmtl blue\nKd 0.1 0.2 0.95\nKs 0.6 0.7 0.8\nillum 2\n"
+           "newmtl red\nKs 0.25 0.5 0.75\nKd 0.125 0.0625 0.5\n")
+    obj = "# an object\nmtllib objload.mtl\n" + "".join(f"v {f3(x)}\n" for x in v) + "".join(f"vn {f3(x)}\n" for x in vn)
+    obj += "".join(f"vt {f3(x)}\n" for x in vt) + "o thing\ng part1\ns 1\n"
+    for i in range(30):
+        a, b, c, d = (int(x) + 1 for x in rs.randint(0, nv, 4))
+        n = [int(x) + 1 for x in rs.randint(0, nn, 4)]
+        t = [int(x) + 1 for x in rs.randint(0, nt, 4)]
+        if i % 7 == 0:
+            obj += ("usemtl " + ["red", "blue", "nothere", "red"][(i // 7) % 4] + "\n")
+        if i == 12:
+            obj += "g part2\n# half way\n"
+        if i % 3 == 0:
+            obj += f"f {a}//{n[0]} {b}//{n[1]} {c}//{n[2]}\n"
+        elif i % 3 == 1:
+            obj += f"f {a}/{t[0]}/{n[0]} {b}/{t[1]}/{n[1]} {c}/{t[2]}/{n[2]}\n"
+        else:
+            obj += f"f {a}/{t[0]}/{n[0]} {b}/{t[1]}/{n[1]} {c}/{t[2]}/{n[2]} {d}/{t[3]}/{n[3]}\n"
+    return obj, mtl
+
+
+OBJLOAD_CASES = [  # scale, translation, rotation in degrees (about x, y, z), lig, col, type
+    (1.0, (0, 0, 0), (0, 0, 0), (0, 0, 0), (.3, .35, .4), 0),
+    (2.5, (10, 20, 30), (0, 0, 90), (.5, .25, .125), (.3, .35, .4), 0),
+    (0.37, (-1.5, 2.25, 7), (30, -45, 60), (0, 0, 0), (.999, .999, .999), 1),
+    (12.0, (50, -3, 81.5), (12.5, 200, -33), (4, 4, 4), (.1, .2, .3), 2),
+]
+
+
+def make_objload():
+    import tempfile
+    obj, mtl = objload_files()
+    d = tempfile.mkdtemp(prefix="objload_")
+    with open(os.path.join(d, "objload.obj"), "w") as f:
+        f.write(obj)
+    with open(os.path.join(d, "objload.mtl"), "w") as f:
+        f.write(mtl)
+    fx = {"obj": np.frombuffer(obj.encode(), np.uint8), "mtl": np.frombuffer(mtl.encode(), np.uint8), "n_cases": np.int32(len(OBJLOAD_CASES)),
+          "params": np.array([[c[0], *c[1], *c[2], *c[3], *c[4], c[5]] for c in OBJLOAD_CASES], np.float64)}
+    for k, (times, loc, rot, lig, col, typ) in enumerate(OBJLOAD_CASES):
+        r = po.RefScene().readfile(os.path.join(d, "objload.obj"), times, loc, rot, lig, col, typ)
+        assert r is not None and not r["has_tex"].any()
+        for name in ("verts", "col", "lig", "ts", "nc", "type"):
+            fx[f"c{k}_{name}"] = r[name]
+    np.savez_compressed(os.path.join(HERE, "objload.npz"), **fx)
+    print("objload", len(OBJLOAD_CASES), "cases,", len(fx["c0_verts"]), "polygons each")
+
+
 if __name__ == "__main__":
     po.build()
     assert po.ref_available(), "oracle/_ref/libref_l3.so is missing (needs /root/reference)"
@@ -183,3 +242,4 @@ if __name__ == "__main__":
     make("deeptree", scenes.deep_tree(), np.array([250, 250, 250.0]), 450.0, 1500)  # a 42-level tree
     make_aabb()
     make_primary()
+    make_objload()

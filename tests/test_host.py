@@ -233,3 +233,39 @@ def test_obj_reader_extensions_are_opt_in(ra, tmp_path):
     assert np.array_equal(t["verts"][:3].reshape(3, 3, 3)[:, 0], np.zeros((3, 3)))
     assert np.array_equal(t["verts"][2].reshape(3, 3), [[0, 0, 0], [0, 1, 0], [0.5, 2, 0]])
     assert np.array_equal(t["tri_ts"][2], [0, 0, 0, 1, .5, 2])
+
+
+def test_image_files_that_cannot_be_decoded_are_errors_and_headers_are_not_trusted(ra, tmp_path):
+    """The reference leaves a material untextured only when the image cannot be OPENED (opencvlib.cpp:13-14); a file
+    that exists is decoded by cv::imread.  A format this reader does not know therefore fails the OBJ load by name
+    instead of rendering flat colours; a header that states an absurd size is refused before anything is allocated."""
+    (tmp_path / "pic.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 0.1 0.2 0.3\nmap_Kd pic.png\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n")
+    hs = ra.HostScene()
+    with pytest.raises(ra.capi.RtError, match=r"decode image .*pic\.png.*BMP"):
+        hs.add_obj_file(tmp_path / "m.obj", 1, (0, 0, 0), (0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    with pytest.raises(ra.capi.RtError, match="Can't open image"):
+        hs.load_texture_file(tmp_path / "nothere.bmp")
+
+    def bmp_header(w, h, bpp=24):
+        return (b"BM" + struct.pack("<IHHI", 54, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, w, h, 1, bpp, 0, 0, 0, 0, 0, 0))
+
+    for w, h in ((0x7FFFFFF0, 0x7FFFFFF0), (3, -0x80000000), (70000, 2), (40000, 40000)):
+        (tmp_path / "huge.bmp").write_bytes(bmp_header(w, h) + b"\0" * 64)
+        with pytest.raises(ra.capi.RtError, match="pixels"):
+            hs.load_texture_file(tmp_path / "huge.bmp")
+    (tmp_path / "huge.ppm").write_bytes(b"P6\n60000 60000\n255\n" + b"\0" * 64)
+    with pytest.raises(ra.capi.RtError, match="pixels"):
+        hs.load_texture_file(tmp_path / "huge.ppm")
+    (tmp_path / "short.bmp").write_bytes(bmp_header(64, 64) + b"\0" * 64)  # fewer bytes than the header promises
+    with pytest.raises(ra.capi.RtError, match="decode"):
+        hs.load_texture_file(tmp_path / "short.bmp")
+    img = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)
+    from raytrace_amd import scenes
+    scenes.write_bmp24(tmp_path / "ok.bmp", img)
+    with pytest.raises(ra.capi.RtError, match="exceeds"):
+        hs.load_texture_file(tmp_path / "ok.bmp", 1e6)
+    k = hs.load_texture_file(tmp_path / "ok.bmp")
+    hs.build()
+    assert np.array_equal(hs.textures()[k], img)

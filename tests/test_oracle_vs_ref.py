@@ -153,3 +153,35 @@ def test_host_builder_equals_the_reference_builder_at_scale(ref, ra):
     assert a["depth"] >= 27 and len(a["axis"]) > 500000
     for k in b:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_obj_reader_equals_the_reference_reader(ref, ra, tmp_path):
+    """Live: rth_add_obj_file against Object::readfile of the reference's object code (object.cpp, matrix.cpp compiled
+    where they lie) on generated OBJ + MTL pairs and random transforms; also that both refuse the same malformed files."""
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).parent / "golden"))
+    import make_golden
+    rs = np.random.RandomState(12)
+    for seed in range(4):
+        obj, mtl = make_golden.objload_files(seed)
+        (tmp_path / "objload.obj").write_text(obj)
+        (tmp_path / "objload.mtl").write_text(mtl)
+        for typ in (0, 1, 2):
+            times, loc, rot = float(rs.uniform(0.1, 20)), rs.uniform(-50, 50, 3), rs.uniform(-360, 360, 3)
+            lig, col = rs.uniform(0, 2, 3), rs.uniform(0, 1, 3)
+            want = ref.RefScene().readfile(tmp_path / "objload.obj", times, loc, rot, lig, col, typ)
+            hs = ra.HostScene()
+            hs.add_obj_file(tmp_path / "objload.obj", times, loc, rot, lig, col, typ)
+            hs.build()
+            t, d = hs.tree_arrays(), hs.desc.contents
+            n = hs.num_tris
+            assert n == len(want["verts"])
+            assert np.array_equal(t["verts"], want["verts"]) and np.array_equal(t["col"], want["col"])
+            assert np.array_equal(t["tri_ts"], want["ts"]) and np.array_equal(t["nc"], want["nc"], equal_nan=True)  # (a face naming a vertex twice has no normal)
+            assert np.array_equal(np.ctypeslib.as_array(d.tri_lig, shape=(n, 3)), want["lig"])
+            assert np.array_equal(np.ctypeslib.as_array(d.tri_type, shape=(n,)), want["type"])
+    for bad in ("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 9//1\n", "v 0 0\nf 1 2 3\n", "v 0 0 0\nvn 0 0 1\nf 1//1 2//\n"):
+        (tmp_path / "bad.obj").write_text(bad)
+        assert ref.RefScene().readfile(tmp_path / "bad.obj", 1, (0, 0, 0), (0, 0, 0), (0, 0, 0), (1, 1, 1), 0) is None
+        with pytest.raises(ra.capi.RtError):
+            ra.HostScene().add_obj_file(tmp_path / "bad.obj", 1, (0, 0, 0), (0, 0, 0), (0, 0, 0), (1, 1, 1), 0)

@@ -34,6 +34,16 @@ def test_noalloc_entry_point_matches_the_allocating_one(ra):
         tiles = frame.plan_tiles(sizex, sizey, tr, tc)[::every]
         want = _render(dev, dev.render_tiles_device, cam, prm, tiles)
         got = _render(dev, dev.render_tiles_noalloc, cam, prm, tiles)
+        # the entry point itself leaves the device's free memory as it found it
+        import torch
+        n = frame.tile_pixels(tiles)
+        buf = torch.zeros((n, 3), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(0)[0]
+        dev.render_tiles_noalloc(cam, prm, tiles, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] == free_before
+        assert np.array_equal(buf.cpu().numpy(), want[0])
         assert np.array_equal(got[0], want[0])
         assert np.array_equal(got[1], want[1])
         assert got[2] == want[2]
