@@ -77,7 +77,8 @@ def test_lucy_class_at_its_benchmark_size(ra, po):
     cam, prm = ra.capi.make_camera(sc["camera"]["o"], sc["camera"]["d"], 24, 40), ra.capi.make_params(**kw)
     whole, wid, wst = dev.render_tile(cam, prm, 0, 0, 24, 40)
     again, aid, ast = dev.render_tile(cam, prm, 0, 0, 24, 40)
-    assert np.array_equal(whole, again) and np.array_equal(wid, aid) and wst == ast
+    work = lambda st: {k: v for k, v in st.items() if not k.startswith("sched_")}  # noqa: E731  (scheduler steps depend on timing)
+    assert np.array_equal(whole, again) and np.array_equal(wid, aid) and work(wst) == work(ast)
     import torch
     for tr, tc in ((7, 9), (16, 16)):  # ragged tilings through the device-buffer entry point
         tiles = frame.plan_tiles(24, 40, tr, tc)
@@ -123,7 +124,8 @@ def test_one_prepared_scene_uploads_twice_to_identical_frames(ra):
     prep.close()  # the uploads own their copies
     for d in (a, b):
         got = d.render_tile(cam, prm, 0, 0, 40, 64)
-        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert {k: v for k, v in got[2].items() if not k.startswith("sched_")} == {k: v for k, v in want[2].items() if not k.startswith("sched_")}
         d.close()
     with pytest.raises(ra.capi.RtError, match="not in"):
         ra.DeviceScene(ra.PreparedScene(hs), 4096)
@@ -142,13 +144,23 @@ def test_kernel_time_is_reported_per_launch_with_two_frames_in_flight(ra):
     b1 = torch.zeros((600 * 800, 3), dtype=torch.float64, device="cuda:0")
     b2 = torch.zeros((16 * 16, 3), dtype=torch.float64, device="cuda:0")
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    dev.render_tiles_device(small, prm, [(0, 0, 16, 16)], b2.data_ptr(), None, s2.cuda_stream)  # warm both sets
+    dev.render_tiles_device(small, prm, [(0, 0, 16, 16)], b2.data_ptr(), None, s2.cuda_stream)  # the second stream brings the second set
+    torch.cuda.synchronize()
+    ms_small_alone = dev.last_kernel_ms()
     dev.render_tiles_device(big, prm, frame.plan_tiles(600, 800), b1.data_ptr(), None, s1.cuda_stream)
     torch.cuda.synchronize()
     ms_big_alone = dev.last_kernel_ms()
+    assert 0 < ms_small_alone < 0.5 * ms_big_alone, (ms_small_alone, ms_big_alone)
+    # both in flight, the big one queued last: the figure is the big one's (each set has its own pair of events)
+    dev.render_tiles_device(small, prm, [(0, 0, 16, 16)], b2.data_ptr(), None, s2.cuda_stream)
+    dev.render_tiles_device(big, prm, frame.plan_tiles(600, 800), b1.data_ptr(), None, s1.cuda_stream)
+    ms_last = dev.last_kernel_ms()
+    assert ms_last > 0.5 * ms_big_alone, (ms_last, ms_big_alone)
+    # the other way round the small launch is the last one: it may have had to wait for the big one's workgroups to leave
+    # the chip (the grid is persistent), but its figure is its own pair's, bounded by both
     dev.render_tiles_device(big, prm, frame.plan_tiles(600, 800), b1.data_ptr(), None, s1.cuda_stream)
     dev.render_tiles_device(small, prm, [(0, 0, 16, 16)], b2.data_ptr(), None, s2.cuda_stream)
-    ms_small = dev.last_kernel_ms()  # the small launch was queued last
+    ms_last = dev.last_kernel_ms()
     torch.cuda.synchronize()
-    assert 0 < ms_small < 0.5 * ms_big_alone, (ms_small, ms_big_alone)
+    assert 0 < ms_last < 2.5 * ms_big_alone, (ms_last, ms_big_alone)
     dev.close()
