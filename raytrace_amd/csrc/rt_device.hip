@@ -102,10 +102,13 @@ constexpr int DEEP_TREE = 28; // tree depth from which the 8-level ring is used
 constexpr int slot_stride(int slots) { return (slots + 31) & ~31; }
 constexpr int MAX_SPLIT = 4;  // pending glass branches per path
 #ifdef RT_PROFILE
-constexpr int N_STATS = 25; // 11..20: clock ticks in vote, the four bodies, tail; steps per kind; 21..24: triangle step details
+constexpr int N_STATS = 28; // 11..20: clock ticks in vote, the four bodies, tail; steps per kind; 21..24: triangle step details; 25..27: ticks from a body's start to the arrival of its loads (node, cull, tri)
 #elif defined(RT_EVENTS)
-constexpr int N_EVENTS = 20;
+constexpr int N_EVENTS = 22;
 constexpr int N_STATS = 11 + 2 * N_EVENTS; // 11..: per event, the steps in which some lane met it, and the lanes that did
+#elif defined(RT_DRAIN) // when the wavefronts start, find the work counter dry, and end (100 MHz clock): how a launch ramps up and drains
+constexpr int DRAIN_BINS = 300; // wavefronts by the time from dry to end, bins of 10 us
+constexpr int N_STATS = 11 + 8 + DRAIN_BINS + 8; // 11 min start, 12 max start, 13 min dry, 14 sum dry, 15 max dry, 16 sum end, 17 max end, 18 wavefronts; after the bins: steps and lanes per kind once the counter is dry
 #else
 constexpr int N_STATS = 11;
 #endif
@@ -213,6 +216,7 @@ struct DevScene {
     const ListHdr *lhdr; // per node
     float fslack;    // part of the single-precision slab test's safety margin that depends on the scene only
     double padc;   // constant part of the node-box padding: 2.5e-5 + 4e-12 * (largest sum of |box coordinates| of a node)
+    float padcf;   // the same in single precision, rounded up
     int n_sph;
     int ovf_depth;
     int n_slots;
@@ -506,6 +510,9 @@ constexpr int LS_WORDS = LS_PEND + PEND_WORDS * (MAX_SPLIT + 1); // (+ 1: a boun
 // number of far children that are only counted (9-11), number of stack levels that live in HBM only (12-19), "the ray
 // starts far outside the scene" (20)
 constexpr unsigned ST_SP = 0xFFu, ST_FLAG = 0x100u, ST_FAR = 1u << 20; // (ST_FAR: see sG)
+// "the ray is tame" (21): every direction component exceeds 2.5e-5 in magnitude and the node-box padding at its origin is
+// below 3e-5 -- what the node step's quick acceptance needs of the ray itself, decided once when the ray starts
+constexpr unsigned ST_TAME = 1u << 21;
 constexpr int ST_LO = 12;
 // Far children that are only counted (their box is certainly missed) when the near subtree returns false need no
 // stack entry if nothing else waits for that return: the frame keeps their number (up to seven) in three bits of its flags word,
@@ -639,7 +646,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
 
 
 #ifdef RT_PROFILE
-    unsigned long long p_vote = 0, p_body[4] = {0, 0, 0, 0}, p_tail = 0, p_n[4] = {0, 0, 0, 0}, p_tri[4] = {0, 0, 0, 0};
+    unsigned long long p_vote = 0, p_body[4] = {0, 0, 0, 0}, p_tail = 0, p_n[4] = {0, 0, 0, 0}, p_tri[4] = {0, 0, 0, 0}, p_load[3] = {0, 0, 0};
 #define RT_TICK(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
 #else
 #define RT_TICK(x)
@@ -654,6 +661,11 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
 #define RT_MARK(name) asm volatile("; RTMARK " name)
 #else
 #define RT_MARK(name)
+#endif
+#ifdef RT_DRAIN
+    const unsigned long long dr_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dr_dry = 0;
+    unsigned dr_steps[4] = {0, 0, 0, 0}, dr_lanes[4] = {0, 0, 0, 0};
 #endif
     for (;;) {
         RT_TICK(tk0);
@@ -678,6 +690,12 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         double *const ls = S.lstate + gslot0 + slot; // this slot's column of the HBM state
         RT_SCOUNT(c_iters, 1);
         RT_SCOUNT(c_lanes, nrun);
+#ifdef RT_DRAIN
+        if (dr_dry != 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (pick == k) { dr_steps[k]++; dr_lanes[k] += (unsigned)nrun; }
+        }
+#endif
 
         // the stack: levels [slo, sp) are in the LDS ring (level i at i mod LDS_STACK), levels [0, slo) in HBM
         int sp = (int)(st & ST_SP), slo = (int)((st >> ST_LO) & 0xFFu);
@@ -732,7 +750,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 }
             }
             bool skipped = false, skipped_far = false; // a child's visit was decided here (it is still a visit of the reference)
-            bool ev_exact = false, ev_fail = false;
+            bool ev_exact = false, ev_fail = false, ev_beyond = false;
             if (run && !refill && !marker) { // ---- enter a node (kdtree.cpp:111-141)
                 const double2 *p = (const double2 *)(S.pool + (size_t)cur * 16);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
@@ -740,6 +758,10 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 const uint4 k0 = kp[0], k1 = kp[1], k2 = kp[2];
                 const float gfac = exp_up_get(sG[sl]);
                 const double2 a = sA[sl], b = sB[sl], c = sC[sl];
+#ifdef RT_PROFILE
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                p_load[0] += __builtin_amdgcn_s_memtime() - tk1;
+#endif
                 const double s[3] = {a.x, a.y, b.x}, inv[3] = {b.y, c.x, c.y};
                 const double mi[3] = {q0.x, q0.y, q1.x}, ma[3] = {q1.y, q2.x, q2.y};
                 const double split = q3.x;
@@ -756,33 +778,47 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 //    `pad`), far inside the eps tolerance of the reference's face test, so its
                 //    loop accepts on that axis.
                 // Whatever is left (grazing rays, nearly axis-parallel directions) runs the exact code.
-                const double pad = S.padc + 4e-12 * (fabs(s[0]) + fabs(s[1]) + fabs(s[2]));
-                double tin = -1e300, tout = 1e300, imax = 0.0;
+                // (the ray's own part of these conditions -- |direction components| > 2.5 eps, padding below 3e-5 -- is the
+                // ray's "tame" flag; the origin-inside test compares the differences the slab parameters need anyway
+                // against eps less 1e-9, which implies the reference's own comparison for every origin such a padding
+                // allows (|coordinates| below 1.25e6: rounding below 1.5e-10).  A lane that neither test accepts -- a node
+                // that is missed, mostly -- goes through the full set of conditions below.)
+                double tin = -1e300, tout = 1e300;
+                bool in1 = true;
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
-                    const double t1 = (mi[i] - s[i]) * inv[i], t2 = (ma[i] - s[i]) * inv[i];
+                    const double d1 = mi[i] - s[i], d2 = ma[i] - s[i];
+                    const double t1 = d1 * inv[i], t2 = d2 * inv[i];
                     tin = fmax(tin, fmin(t1, t2)); tout = fmin(tout, fmax(t1, t2));
-                    imax = fmax(imax, fabs(inv[i]));
+                    in1 &= (d1 < EPS * (1 - 1e-4)) & (d2 > -EPS * (1 - 1e-4));
                 }
-                // growing the box by `pad` moves every slab parameter by at most pad * max|1/direction|
-                const double pm = pad * imax;
-                const bool maybe = (tin - pm <= tout + pm) & (tout + pm >= 0.0);
-                const bool inside = (mi[0] < s[0] + EPS) & (s[0] < ma[0] + EPS) & (mi[1] < s[1] + EPS) & (s[1] < ma[1] + EPS) &
-                                    (mi[2] < s[2] + EPS) & (s[2] < ma[2] + EPS);
-                const bool clear = (tin <= tout) & (tin > 2e-5) & (imax < 4e4) & (pad < 3e-5);
                 const int axis = info & 3;
                 const double sw = axis == 0 ? s[0] : axis == 1 ? s[1] : s[2];
                 const double iw = axis == 0 ? inv[0] : axis == 1 ? inv[1] : inv[2];
-                bool pass = inside | clear;
+                bool pass = ((st & ST_TAME) != 0) & (in1 | ((tin <= tout) & (tin > 2e-5)));
                 bool vpos = iw > 0, vneg = iw < 0; // sign of the direction along the split axis
-                ev_exact = (maybe & !pass) | (fabs(iw) >= 1e299);
-                if (__builtin_expect((maybe & !pass) | (fabs(iw) >= 1e299), 0)) { // rare: needs the direction itself
-                    const double v[3] = {ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]};
-                    if (!pass) pass = maybe && aabb_hit(mi, ma, s, v);
-                    const double vw = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
-                    vpos = vw > 0; vneg = vw < 0;
+                if (__builtin_expect(!pass | (fabs(iw) >= 1e299), 0)) { // one lane in a thousand
+                    const double pad = S.padc + 4e-12 * (fabs(s[0]) + fabs(s[1]) + fabs(s[2]));
+                    const double imax = fmax(fmax(fabs(inv[0]), fabs(inv[1])), fabs(inv[2]));
+                    // growing the box by `pad` moves every slab parameter by at most pad * max|1/direction|
+                    const double pm = pad * imax;
+                    const bool maybe = (tin - pm <= tout + pm) & (tout + pm >= 0.0);
+                    const bool inside = (mi[0] < s[0] + EPS) & (s[0] < ma[0] + EPS) & (mi[1] < s[1] + EPS) & (s[1] < ma[1] + EPS) &
+                                        (mi[2] < s[2] + EPS) & (s[2] < ma[2] + EPS);
+                    const bool clear = (tin <= tout) & (tin > 2e-5) & (imax < 4e4) & (pad < 3e-5);
+                    pass = inside | clear;
+                    ev_exact = (maybe & !pass) | (fabs(iw) >= 1e299);
+                    if ((maybe & !pass) | (fabs(iw) >= 1e299)) { // rare: needs the direction itself
+                        const double v[3] = {ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]};
+                        if (!pass) pass = maybe && aabb_hit(mi, ma, s, v);
+                        const double vw = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
+                        vpos = vw > 0; vneg = vw < 0;
+                    }
                 }
                 ev_fail = !pass;
+#ifdef RT_EVENTS
+                ev_beyond = pass && tin > (double)half_up_get(sT[sl]);
+#endif
                 if (!pass) want_pop = true;
                 else {
                     l_tris += info >> 3; // the own list will be scanned (kdtree.cpp:122,131,137)
@@ -815,7 +851,9 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                         // the list's inflation, as the step that starts the list would compute it
                         const float mgl = ldexpf(__uint_as_float(k2.z), (st & ST_FAR) ? (int)(k2.z & 0xFFu) : 0) * gfac;
                         // one inflation for all three boxes, the larger of the two (a larger one only skips less)
-                        const float mt = (fmaxf((float)(pad * 1.000001), mgl) + msl) * 1.000001f;
+                        // (the node-box padding, rounded up: S.padcf >= padc, 4.1e-12f * |origin|_1 in single precision >= 4e-12 * |origin|_1)
+                        const float padf = S.padcf + 4.1e-12f * (fabsf(sf[0]) + fabsf(sf[1]) + fabsf(sf[2]));
+                        const float mt = (fmaxf(padf, mgl) + msl) * 1.000001f;
                         f2 ka[3], kb[3];
 #pragma unroll
                         for (int i = 0; i < 3; i++) {
@@ -897,13 +935,14 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
             }
             RT_EV(0, run && !refill && !marker); RT_EV(1, ev_exact); RT_EV(2, refill); RT_EV(3, marker); RT_EV(4, ev_fail);
             RT_EV(16, run && !refill && !marker && !ev_fail && next != 0 && !want_pop && push_item == 0); // goes on without a push
+            RT_EV(20, ev_beyond); // the node's box lies beyond the best hit so far
             const bool fetched = run && !refill && !marker; // lanes that fetched a node's records
             l_nf += fetched ? 1u : 0u;
             vis_add += (fetched ? 1u : 0u) + (skipped ? 1u : 0u) + (skipped_far ? 1u : 0u);
         } else if (pick == K_CULL) {
             RT_MARK("cull");
             bool boxes = false;
-            bool ev_one = false;
+            bool ev_one = false, ev_lim = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
                 const unsigned g = (cur & IT_AFTER) ? S.g_list + after_granule(cur) : (cur & IDX28);
                 const uint4 *p = (const uint4 *)(S.pool + (size_t)g * 16);
@@ -928,6 +967,10 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 asm volatile("" : : "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w), "v"(r2.x), "v"(r2.y),
                              "v"(r2.z), "v"(r2.w), "v"(it.x), "v"(it.y), "v"(it.z), "v"(it.w), "v"(hdr.x), "v"(hdr.y));
                 if (SPH) asm volatile("" : : "v"(sph_best));
+#endif
+#ifdef RT_PROFILE
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                p_load[1] += __builtin_amdgcn_s_memtime() - tk1;
 #endif
                 ev_one = it.y == 0 && it.z == 0 && it.w == 0 && (it.x >> 30) != 0; // (diagnostics)
                 const bool lim_on = sph_boxes || ((st & ST_FLAG) != 0) || ((cur & IT_AFTER) && ((cur >> 30) & 1));
@@ -1010,6 +1053,9 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                         }
                         const float tmin = fmaxf(fmaxf(ta[0], ta[1]), fmaxf(ta[2], 0.0f)), tmax = fminf(fminf(tb[0], tb[1]), fminf(tb[2], tlim));
                         hit[k] = (tmin * 0.999999f <= tmax) & (item[k] != 0);
+#ifdef RT_EVENTS
+                        if (hit[k] && !(tmin * 0.999999f <= fminf(tmax, best_lim * 1.000001f))) ev_lim = true;
+#endif
                     }
                     // the first child that is met continues, the others go on the stack
                     const int n1 = hit[0], n2 = n1 + hit[1], n3 = n2 + hit[2], n4 = n3 + hit[3];
@@ -1040,6 +1086,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
             }
             RT_EV(5, run && (cur & IT_AFTER)); RT_EV(6, boxes); RT_EV(7, boxes && want_pop); RT_EV(8, run && !boxes);
             RT_EV(18, boxes && want_pop && (cur & IT_AFTER)); // a list whose first record already meets nothing
+            RT_EV(21, ev_lim); // a box that is met lies beyond the best hit so far (and the frame has no hit)
             RT_EV(19, run && (cur & IT_AFTER) && ev_one); // a list that is one triangle item, entered after a near subtree
             l_culls += boxes ? 1u : 0u;
         } else if (pick == K_TRI) {
@@ -1075,6 +1122,10 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 for (int k = 0; k < GROUP - 1; k++)
                     asm volatile("" : : "v"(u[k][0].x), "v"(u[k][0].y), "v"(u[k][1].x), "v"(u[k][1].y), "v"(u[k][2].x), "v"(u[k][2].y), "v"(u[k][3].x),
                                  "v"(u[k][3].y), "v"(u[k][4].x), "v"(u[k][4].y));
+#endif
+#ifdef RT_PROFILE
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                p_load[2] += __builtin_amdgcn_s_memtime() - tk1;
 #endif
                 const d3 o = mk(a.x, a.y, b.x);
                 if (is_sph) { // ---- one sphere of the sphere hierarchy (sphere.h:13-21, sphere.cpp:7)
@@ -1452,6 +1503,11 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     sG[sl] = exp_up_put(gf);
                     // beyond the factor (4 * reach + 1 at upload) that the lists' working coefficients cover: the larger ones
                     st = gf <= (float)(3.9 * C.reach) ? 0u : ST_FAR;
+                    { // (see the node step)
+                        const double imax = fmax(fmax(fabs(ix), fabs(iy)), fabs(iz));
+                        const double pad = S.padc + 4e-12 * (fabs(ro.x) + fabs(ro.y) + fabs(ro.z));
+                        if ((imax < 4e4) & (pad < 3e-5)) st |= ST_TAME;
+                    }
                     sp = 0; slo = 0;
                     if (SPH) { // many spheres: their hierarchy is searched after the kd-tree, from the bottom of the stack
                         const bool unit = fabs(dot(rd, rd) - 1.0) <= 1e-12; // what the boxes' inflation assumes
@@ -1472,6 +1528,9 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         // ---- common tail for the lanes that ran: push, pop, publish the slot's next item
         RT_TICK(tk2);
         RT_MARK("tail");
+#ifdef RT_DRAIN
+        if (dr_dry == 0 && __ballot(done)) dr_dry = __builtin_amdgcn_s_memrealtime();
+#endif
         RT_EV(11, run && push_item != 0); RT_EV(12, run && push_item != 0 && sp - slo == LDS_STACK); RT_EV(13, run && want_pop);
         RT_EV(17, run && want_pop && sp <= slo && sp != 0); // the popped level is in HBM
         if (run) {
@@ -1510,7 +1569,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
             const int i2 = 2 * wslot0 + SLOTS + q2 + rank(m2), i3 = 2 * wslot0 + 2 * SLOTS - 1 - q3 - rank(m3);
             const int qi = nk == K_NODE ? i0 : nk == K_CULL ? i1 : nk == K_TRI ? i2 : i3;
             if (nk != K_DONE)
-                sQ[qi] = make_uint2((unsigned)slot | (((st & (ST_FLAG | ST_N | ST_FAR)) | (unsigned)sp | ((unsigned)slo << ST_LO)) << 8), next == IT_END ? 0u : next);
+                sQ[qi] = make_uint2((unsigned)slot | (((st & (ST_FLAG | ST_N | ST_FAR | ST_TAME)) | (unsigned)sp | ((unsigned)slo << ST_LO)) << 8), next == IT_END ? 0u : next);
             q0 += __popcll(m0); q1 += __popcll(m1); q2 += __popcll(m2); q3 += __popcll(m3);
         }
 #ifdef RT_PROFILE
@@ -1524,12 +1583,25 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
     if (lane == 0) {
         atomicAdd(gstats + 11, p_vote); atomicAdd(gstats + 16, p_tail);
         for (int k = 0; k < 4; k++) { atomicAdd(gstats + 12 + k, p_body[k]); atomicAdd(gstats + 17 + k, p_n[k]); atomicAdd(gstats + 21 + k, p_tri[k]); }
+        for (int k = 0; k < 3; k++) atomicAdd(gstats + 25 + k, p_load[k]);
     }
 #endif
 
 #ifdef RT_EVENTS
     if (lane == 0)
         for (int k = 0; k < N_EVENTS; k++) { atomicAdd(gstats + 11 + 2 * k, p_ev[k]); atomicAdd(gstats + 12 + 2 * k, p_evl[k]); }
+#endif
+#ifdef RT_DRAIN
+    if (lane == 0) {
+        const unsigned long long dr_end = __builtin_amdgcn_s_memrealtime();
+        if (dr_dry == 0) dr_dry = dr_end;
+        atomicMax(gstats + 11, ~0ull - dr_start); // (the counters start at zero: minima are kept as maxima of the complement)
+        atomicMax(gstats + 12, dr_start);
+        atomicMax(gstats + 13, ~0ull - dr_dry); atomicAdd(gstats + 14, dr_dry - dr_start); atomicMax(gstats + 15, dr_dry);
+        atomicAdd(gstats + 16, dr_end - dr_start); atomicMax(gstats + 17, dr_end); atomicAdd(gstats + 18, 1ull);
+        { const unsigned long long b = (dr_end - dr_dry) / 1000ull; atomicAdd(gstats + 19 + (b < DRAIN_BINS ? b : DRAIN_BINS - 1), 1ull); }
+        for (int k = 0; k < 4; k++) { atomicAdd(gstats + 19 + DRAIN_BINS + k, (unsigned long long)dr_steps[k]); atomicAdd(gstats + 23 + DRAIN_BINS + k, (unsigned long long)dr_lanes[k]); }
+    }
 #endif
     // ---- work counters
     flush();
@@ -2559,6 +2631,7 @@ int rt_prepare_scene(const rt_scene_desc *D, rt_prepared **out) {
         if (!(b <= boxsum)) boxsum = b; // also takes a NaN, which then disables the shortcut
     }
     P->d.padc = 2.5e-5 + 4e-12 * boxsum;
+    P->d.padcf = f_up(P->d.padc * 1.000002);
     P->d.g_list = (unsigned)g_list;
     P->d.g_tri = (unsigned)g_tri;
     P->d.g_sph = (unsigned)g_sph;
@@ -2788,12 +2861,27 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
         static const char *en[N_EVENTS] = {"node: record fetched", "node: exact check_aabb code", "node: refill", "node: marker", "node: box not met",
                                            "cull: after item", "cull: boxes tested", "cull: no box met", "cull: short list / none", "tri: step",
                                            "tri: frame has a hit", "tail: push", "tail: push moves a level to HBM", "tail: pop", "tail: marker popped",
-                                           "tail: traversal ends", "node: goes on without a push", "tail: popped level is in HBM", "cull: list's first record meets no box", "cull: list of one item after a near subtree"};
+                                           "tail: traversal ends", "node: goes on without a push", "tail: popped level is in HBM", "cull: list's first record meets no box", "cull: list of one item after a near subtree",
+                                           "node: box beyond the best hit", "cull: a met box lies beyond the best hit"};
         const double iters = (double)h[ST_ITERS], rays = (double)h[ST_RAYS];
         for (int k = 0; k < N_EVENTS; k++)
             if (en[k][0])
                 fprintf(stderr, "[events] %-34s steps %6.2f%% of all  lanes/ray %7.3f  lanes per such step %5.1f\n", en[k], 100.0 * h[11 + 2 * k] / iters,
                         h[12 + 2 * k] / rays, h[11 + 2 * k] ? (double)h[12 + 2 * k] / h[11 + 2 * k] : 0.0);
+    }
+#endif
+#ifdef RT_DRAIN
+    if (h[18]) { // (one launch between two calls: the extremes are those of that launch)
+        const double t0 = (double)(~0ull - h[11]), w = (double)h[18], us = 0.01; // 100 MHz ticks
+        fprintf(stderr, "[drain] wavefronts %.0f  last start %.1f us  counter dry: first %.1f mean %.1f last %.1f us  end: mean %.1f last %.1f us\n", w,
+                ((double)h[12] - t0) * us, ((double)(~0ull - h[13]) - t0) * us, (double)h[14] / w * us, ((double)h[15] - t0) * us,
+                (double)h[16] / w * us, ((double)h[17] - t0) * us);
+        fprintf(stderr, "[drain] wavefronts by the time from dry to end, bins of 10 us:");
+        for (int b = 0; b < DRAIN_BINS; b++) if (h[19 + b]) fprintf(stderr, " %d:%llu", b, h[19 + b]);
+        fprintf(stderr, "\n[drain] after dry, per wavefront:");
+        { static const char *kn[4] = {"node", "cull", "tri", "shade"};
+          for (int k = 0; k < 4; k++) fprintf(stderr, " %s %.1f steps x %.1f lanes", kn[k], (double)h[19 + DRAIN_BINS + k] / w, h[19 + DRAIN_BINS + k] ? (double)h[23 + DRAIN_BINS + k] / h[19 + DRAIN_BINS + k] : 0.0); }
+        fprintf(stderr, "\n");
     }
 #endif
 #ifdef RT_PROFILE
@@ -2806,6 +2894,8 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
             for (int k = 0; k < 4; k++)
                 fprintf(stderr, "[profile]   %-5s steps %5.1f%%  body ticks/step %.1f  share of ticks %.1f%%\n", kn[k], 100.0 * q[6 + k] / steps,
                         q[6 + k] ? (double)q[1 + k] / q[6 + k] : 0.0, 100.0 * q[1 + k] / (double)(q[0] + q[5] + q[1] + q[2] + q[3] + q[4]));
+            for (int k = 0; k < 3; k++)
+                fprintf(stderr, "[profile]   %-5s ticks from the body's start to the arrival of its loads: %.1f per step\n", kn[k], q[6 + k] ? (double)h[25 + k] / q[6 + k] : 0.0);
             fprintf(stderr, "[profile]   triangle tests per ray: short lists %.1f (hit %.2f), behind boxes %.1f (hit %.2f)\n", (double)q[10] / h[0],
                     (double)q[11] / h[0], (double)q[12] / h[0], (double)q[13] / h[0]);
         }
