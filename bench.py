@@ -49,6 +49,8 @@ def build_workload(name, sizex, sizey):
     from raytrace_amd import scenes
     if name == "sponza":
         return scenes.sponza_class(262267, sizex or 2160, sizey or 3840), dict(rr_depth=5, rr_mode=0)
+    if name == "sponza_tex":  # the same geometry with images on floor, ceiling and walls: the textured kernel instance
+        return scenes.sponza_class(262267, sizex or 2160, sizey or 3840, textured=True), dict(rr_depth=5, rr_mode=0)
     if name == "bunny":
         return scenes.bunny_class(69451, sizex or 1080, sizey or 1920), dict(rr_depth=2, rr_mode=0)
     if name == "spheres":

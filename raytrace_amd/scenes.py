@@ -251,11 +251,12 @@ def random_spheres(n=10000, sizex=1080, sizey=1920, seed=42):
             "camera": {"o": np.array([50, 50, 300.0]), "d": np.array([0, 0, -1.0])}, "sizex": sizex, "sizey": sizey}
 
 
-def sponza_class(n_tris=262267, sizex=2160, sizey=3840, seed=3, detail=1.0):
+def sponza_class(n_tris=262267, sizex=2160, sizey=3840, seed=3, detail=1.0, textured=False):
     """A closed colonnaded atrium of exactly n_tris triangles (axis-heavy walls, slabs and floor
     plus fluted columns, arches, hanging drapes, urns and a relief), lit by 2 emissive spheres:
     stand-in for Crytek Sponza.  `detail` scales the tessellation of everything but the floor,
-    which absorbs the remainder so the total is exact."""
+    which absorbs the remainder so the total is exact.  `textured`: the same geometry with images
+    (test_images) on the floor, the ceiling and the two long walls (Polygon::getcol, polygon.h:73-89)."""
     rs = np.random.RandomState(seed)
     q = lambda v: max(2, int(round(v * detail)))  # noqa: E731
     X0, X1, Y0, Y1, Z0, Z1 = -20.0, 120.0, 0.0, 80.0, 0.0, 280.0  # every camera ray starts inside (z <= 275.6)
@@ -315,9 +316,19 @@ def sponza_class(n_tris=262267, sizex=2160, sizey=3840, seed=3, detail=1.0):
     fc = np.where(np.concatenate([chk, chk])[:, None] == 0, np.array(stone), np.array((.45, .42, .4)))
     meshes.append(_mesh(floor, stone, DIFF, tri_cols=fc))
     meshes.append(_mesh(fan((50, 0.02, 131), 12.0, k), (.55, .25, .2)))
-    scene = {"name": f"sponza_class_{n_tris}", "meshes": meshes,
+    if textured:  # (texture coordinates follow grid()'s own parametrisation; they stay non-negative)
+        def put(i, nu_, nv_, tex, reps):
+            n = meshes[i]["verts"].shape[0]
+            meshes[i] = dict(meshes[i], tri_tex=np.full(n, tex, np.int32), tri_ts=_grid_uv(nu_, nv_, reps=reps, off=(0.25, 0.25)))
+        put(0, q(40), q(24), 1, 6.0)            # ceiling
+        put(1, q(16), q(48), 0, 9.0)            # left wall
+        put(2, q(48), q(16), 0, 9.0)            # right wall
+        put(len(meshes) - 2, nv, nu, 2, 40.0)   # floor
+    scene = {"name": f"sponza_class_{n_tris}" + ("_textured" if textured else ""), "meshes": meshes,
              "spheres": [_sphere(6, (50, 70, 70), (40, 38, 34), (0, 0, 0), DIFF), _sphere(6, (50, 70, 190), (40, 38, 34), (0, 0, 0), DIFF)],
              "camera": {"o": np.array([50, 40, 400.0]), "d": np.array([0, -0.02, -1.0])}, "sizex": sizex, "sizey": sizey}
+    if textured:
+        scene["textures"] = test_images(seed)
     assert num_tris(scene) == n_tris, (num_tris(scene), n_tris)
     return scene
 

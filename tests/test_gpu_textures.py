@@ -88,3 +88,24 @@ def test_textures_do_not_change_queries_or_untextured_scenes(ra, po):
     _, (r3, p3, s3), (orgb, opid, _) = _frames(ra, po, sc3, 24, 32, kw)
     assert np.array_equal(r2, r3) and np.array_equal(p2, p3) and np.array_equal(p3, opid)
     assert (np.abs(r3 - orgb).max(-1) <= 1e-9).mean() >= 0.999
+
+
+def test_textured_sponza_class_matches_oracle(ra, po):
+    """The textured kernel instance on a real tree: the Sponza-class hall with images on floor, ceiling and the long
+    walls (what `bench.py --workload sponza_tex` times, at a size the oracle finishes in seconds).  Same geometry as
+    the untextured scene, so the primary ids are those of the untextured frame as well."""
+    from raytrace_amd import scenes
+    kw = dict(samps=1, rr_depth=5, rr_mode=0, split_depth=2, hard_depth=64, jitter=1, seed=5)
+    sc = scenes.sponza_class(40000, 54, 96, detail=0.3, textured=True)
+    hs, (rgb, pid, st), (orgb, opid, ost) = _frames(ra, po, sc, 54, 96, kw)
+    assert hs.desc.contents.n_textures == 3
+    assert np.array_equal(pid, opid)
+    tt = hs.tree_arrays()["tri_tex"]
+    hit = pid >= 0
+    assert (tt[pid[hit]] >= 0).mean() > 0.3  # a good part of the primary hits is textured
+    diff = np.abs(rgb - orgb).max(axis=-1)
+    assert (diff <= 1e-9).mean() >= 0.999, float(diff.max())
+    assert abs(st["rays"] - ost["rays"]) <= 1e-3 * ost["rays"] + 2
+    plain = scenes.sponza_class(40000, 54, 96, detail=0.3)
+    _, (rgb0, pid0, _), _ = _frames(ra, po, plain, 54, 96, kw)
+    assert np.array_equal(pid0, pid) and np.abs(rgb0 - rgb).max() > 1e-3  # same hits, other colours

@@ -25,7 +25,8 @@ def main():
     cam = ra.capi.make_camera(scene["camera"]["o"], scene["camera"]["d"], sizex, sizey)
     dev = ra.DeviceScene(host, 0)
     device = torch.device("cuda", 0)
-    tiles = frame.plan_tiles(sizex, sizey, 64, 64)
+    tile = int(os.environ.get("SHARD_TILE", "64"))
+    tiles = frame.plan_tiles(sizex, sizey, tile, tile)
     out = torch.zeros((sizex * sizey, 3), dtype=torch.float64, device=device)
     stream = torch.cuda.current_stream(device).cuda_stream
 
