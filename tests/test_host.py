@@ -152,6 +152,11 @@ def test_scene_generators_hit_their_triangle_counts():
     assert len(s["spheres"]) == 10000 and not s["meshes"]
     a, b = scenes.sponza_class(30000, detail=0.25), scenes.sponza_class(30000, detail=0.25)
     assert all(np.array_equal(x["verts"], y["verts"]) for x, y in zip(a["meshes"], b["meshes"]))  # deterministic
+    # the textured variant is the same geometry; its textured meshes carry one image index and six coordinates per triangle
+    t = scenes.sponza_class(30000, detail=0.25, textured=True)
+    assert all(np.array_equal(x["verts"], y["verts"]) for x, y in zip(a["meshes"], t["meshes"])) and len(t["textures"]) == 3
+    tex = [m for m in t["meshes"] if m.get("tri_tex") is not None]
+    assert len(tex) == 4 and all(m["tri_ts"].shape == (m["verts"].shape[0], 6) and (m["tri_ts"] >= 0).all() for m in tex)
 
 
 def test_obj_with_materials_textures_and_images(ra, tmp_path):
