@@ -294,6 +294,20 @@ __device__ __forceinline__ T *as_global(T *p) {
 #endif
 }
 
+// Addresses as "wavefront-uniform base + 32-bit lane offset": a load or store takes that form as it is, where a 64-bit
+// address per lane costs a shift and two adds of vector arithmetic for every record and every state word (+1.2 % at 4K).
+// The pool holds at most 2^28 granules of 16 bytes (rt_prepare_scene refuses more), so a record's byte offset fits 32 bits.
+__device__ __forceinline__ const char *pool_at(const char *pool, unsigned granule) { return pool + (unsigned)(granule << 4); }
+// A slot's column of the per-slot state in HBM ([word][slot], 8-byte words) for the traversal steps: lw[w * n_slots] is
+// word w of the slot, as with a plain pointer to the slot's first word.  All columns together stay below 4 GiB
+// (rt_upload_prepared checks).  The shade step keeps the plain pointer: with its two dozen different words the uniform
+// bases cost more scalar registers (which the kernel already spills) than the lane arithmetic they save.
+struct SlotWords {
+    char *base;   // the array (uniform)
+    unsigned off; // byte offset of the slot's word in a column
+    __device__ __forceinline__ double &operator[](size_t elems) const { return *(double *)((base + elems * 8) + off); }
+};
+
 // drand48 recurrence; every path restarts it from a hashed state
 __device__ __forceinline__ double rng_next(unsigned long long &x) {
     x = (x * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL;
@@ -688,6 +702,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         const unsigned cur = e.y;
         unsigned st = e.x >> 8;
         double *const ls = S.lstate + gslot0 + slot; // this slot's column of the HBM state
+        const SlotWords lw = {(char *)S.lstate, (gslot0 + (unsigned)slot) * 8u}; // (the same for the traversal steps, see SlotWords)
         RT_SCOUNT(c_iters, 1);
         RT_SCOUNT(c_lanes, nrun);
 #ifdef RT_DRAIN
@@ -752,9 +767,9 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
             bool skipped = false, skipped_far = false; // a child's visit was decided here (it is still a visit of the reference)
             bool ev_exact = false, ev_fail = false, ev_beyond = false;
             if (run && !refill && !marker) { // ---- enter a node (kdtree.cpp:111-141)
-                const double2 *p = (const double2 *)(S.pool + (size_t)cur * 16);
+                const double2 *p = (const double2 *)pool_at(S.pool, cur);
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                const uint4 *kp = (const uint4 *)(S.pool + (size_t)(2u * S.g_list + 3u * (cur >> 2)) * 16); // boxes of the children and the own list
+                const uint4 *kp = (const uint4 *)pool_at(S.pool, 2u * S.g_list + 3u * (cur >> 2)); // boxes of the children and the own list
                 const uint4 k0 = kp[0], k1 = kp[1], k2 = kp[2];
                 const float gfac = exp_up_get(sG[sl]);
                 const double2 a = sA[sl], b = sB[sl], c = sC[sl];
@@ -809,7 +824,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     pass = inside | clear;
                     ev_exact = (maybe & !pass) | (fabs(iw) >= 1e299);
                     if ((maybe & !pass) | (fabs(iw) >= 1e299)) { // rare: needs the direction itself
-                        const double v[3] = {ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]};
+                        const double v[3] = {lw[LS_V * lss], lw[(LS_V + 1) * lss], lw[(LS_V + 2) * lss]};
                         if (!pass) pass = maybe && aabb_hit(mi, ma, s, v);
                         const double vw = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
                         vpos = vw > 0; vneg = vw < 0;
@@ -945,7 +960,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
             bool ev_one = false, ev_lim = false;
             if (run) { // ---- four child boxes of a list's hierarchy; for an after item, the list's start
                 const unsigned g = (cur & IT_AFTER) ? S.g_list + after_granule(cur) : (cur & IDX28);
-                const uint4 *p = (const uint4 *)(S.pool + (size_t)g * 16);
+                const uint4 *p = (const uint4 *)pool_at(S.pool, g);
                 const uint4 r0 = p[0], r1 = p[1], r2 = p[2], it = p[3];
                 // right child, list header (every lane loads, the others node 0's: a load under a branch of its own
                 // makes the compiler wait for all of the loads above before it goes on)
@@ -959,7 +974,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 // a word of the slot's state in HBM that is fetched with the record)
                 const bool sph_boxes = SPH && !(cur & IT_AFTER) && (cur & IDX28) >= S.g_sphc;
                 double sph_best = 0;
-                if (SPH && sph_boxes) sph_best = ls[LS_ST * lss];
+                if (SPH && sph_boxes) sph_best = lw[LS_ST * lss];
 #ifndef RT_NO_CONSUME
                 // Every lane takes delivery of all it loaded, here: a load whose result some path never reads counts as in
                 // flight for the compiler from then on, and it then puts full waits -- which also wait for the stores
@@ -1097,7 +1112,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                 // again: a load under a branch of its own would be waited for separately)
                 const bool grp = (cur >> 29) == 3u;
                 const unsigned gn = grp ? ((cur >> 26) & 3u) + 2u : 1u; // triangles of this step
-                const double2 *p = (const double2 *)(S.pool + (size_t)(grp ? S.g_tri + 5u * (cur & GROUP_POS) : (cur & IDX28)) * 16);
+                const double2 *p = (const double2 *)pool_at(S.pool, grp ? S.g_tri + 5u * (cur & GROUP_POS) : (cur & IDX28));
                 const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
                 const long long w9 = __double_as_longlong(q4.y);
                 double2 u[GROUP - 1][5];
@@ -1108,12 +1123,12 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     for (int i = 0; i < 5; i++) u[k - 1][i] = pk[i];
                 }
                 const bool chain = (cur >> 28) == ((IT_TRI | IT_CHAIN) >> 28);
-                const d3 d = mk(ls[LS_V * lss], ls[(LS_V + 1) * lss], ls[(LS_V + 2) * lss]);
-                const double best_t = ls[LS_BT * lss];
+                const d3 d = mk(lw[LS_V * lss], lw[(LS_V + 1) * lss], lw[(LS_V + 2) * lss]);
+                const double best_t = lw[LS_BT * lss];
                 const double2 a = sA[sl], b = sB[sl];
                 is_sph = SPH && !grp && (cur & IDX28) >= S.g_sph;
                 double sph_ts = 0; // the nearest sphere so far, fetched with the record
-                if (SPH && is_sph) sph_ts = ls[LS_ST * lss];
+                if (SPH && is_sph) sph_ts = lw[LS_ST * lss];
 #ifndef RT_NO_CONSUME
                 if (SPH) asm volatile("" : : "v"(sph_ts));
                 asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q1.x), "v"(q1.y), "v"(q2.x), "v"(q2.y), "v"(q3.x), "v"(q3.y), "v"(q4.x), "v"(q4.y),
@@ -1143,9 +1158,9 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     }
                     const double ts = sph_ts;
                     // the reference scans from the last sphere down with strict <: of equal distances the higher index wins
-                    if (t < ts || (t == ts && t < 1e20 && i > (int)__double_as_longlong(ls[LS_SI * lss]))) {
-                        ls[LS_ST * lss] = t;
-                        ls[LS_SI * lss] = __longlong_as_double((long long)i);
+                    if (t < ts || (t == ts && t < 1e20 && i > (int)__double_as_longlong(lw[LS_SI * lss]))) {
+                        lw[LS_ST * lss] = t;
+                        lw[LS_SI * lss] = __longlong_as_double((long long)i);
                     }
                     want_pop = true;
                 }
@@ -1160,7 +1175,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                         // is the lower rank, across lists it is the list visited first
                         bool better = t < best_cur;
                         if (__builtin_expect(t == best_cur && t < 1e20, 0)) { // rare: the two triangles' lists and ranks decide
-                            const unsigned held = have_new ? new_ha : ((const unsigned *)&ls[LS_HA * lss])[0];
+                            const unsigned held = have_new ? new_ha : ((const unsigned *)&lw[LS_HA * lss])[0];
                             const uint2 lb = S.tlist[held], lc = S.tlist[(unsigned)w & ~TRI_LAST];
                             better = lb.x == lc.x && (int)(w >> 32) < (int)lb.y;
                         }
@@ -1178,9 +1193,9 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                         consider(has ? tri_hit(mk(r[0].x, r[0].y, r[1].x), mk(r[1].y, r[2].x, r[2].y), mk(r[3].x, r[3].y, r[4].x), o, d) : 0.0, __double_as_longlong(r[4].y));
                 }
                 if (have_new) {
-                    ls[LS_BT * lss] = best_cur;
+                    lw[LS_BT * lss] = best_cur;
                     sT[sl] = half_up_put((float)best_cur * 1.000001f); // (t > 0; the factor covers the rounding to single)
-                    ls[LS_HA * lss] = __longlong_as_double((long long)(unsigned long long)new_ha);
+                    lw[LS_HA * lss] = __longlong_as_double((long long)(unsigned long long)new_ha);
                 }
                 if (is_sph) {}
                 else if (chain && !((unsigned)w9 & TRI_LAST)) next = cur + 5u; // the list's next triangle
@@ -1275,7 +1290,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                                 const unsigned tt = (unsigned)type >> 2;
                                 type &= 3;
                                 if (tt) {
-                                    const double2 *p = (const double2 *)(S.pool + (size_t)(2u * S.g_list + 3u * (S.g_list >> 2) + 5u * (unsigned)tpos) * 16);
+                                    const double2 *p = (const double2 *)pool_at(S.pool, 2u * S.g_list + 3u * (S.g_list >> 2) + 5u * (unsigned)tpos);
                                     const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
                                     double u, v;
                                     tri_uv(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, d, u, v);
@@ -1381,7 +1396,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
                     if (!TRACE && !go_on) {
                         if (np > 0) { // resume a parked glass branch
                             --np;
-                            const double *q = ls + (size_t)(LS_PEND + PEND_WORDS * np) * lss;
+                            double *q = ls + (size_t)(LS_PEND + PEND_WORDS * np) * lss;
                             ro = mk(q[0], q[lss], q[2 * lss]); rd = mk(q[3 * lss], q[4 * lss], q[5 * lss]);
                             ls[LS_THR * lss] = q[6 * lss]; ls[(LS_THR + 1) * lss] = q[7 * lss]; ls[(LS_THR + 2) * lss] = q[8 * lss];
                             const unsigned long long w = (unsigned long long)__double_as_longlong(q[9 * lss]);
@@ -2715,6 +2730,10 @@ int rt_upload_prepared(int dev, const rt_prepared *P, rt_scene **out) {
     // one after item per tree level, the far child, one list's hierarchy walk or short list on top
     const int need_depth = tree_depth + 3 * cull_depth + 5 + (sph_root ? 1 : 0);
     const int ovf_depth = need_depth > LDS_STACK ? need_depth - LDS_STACK + 1 : 0; // levels that can move to HBM
+    if ((long long)LS_WORDS * n_slots * (long long)sizeof(double) >= (1ll << 32)) { // (the kernel addresses a state word by a 32-bit byte offset)
+        rt_free_scene(s);
+        return fail(RT_E_LIMIT, "per-slot state of %d slots exceeds 4 GiB", n_slots);
+    }
     if ((long long)ovf_depth * n_slots >= (1ll << 31)) {
         rt_free_scene(s);
         return fail(RT_E_LIMIT, "overflow stack of %d levels x %d slots exceeds the 31-bit index", ovf_depth, n_slots);
