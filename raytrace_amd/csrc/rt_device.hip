@@ -40,6 +40,9 @@
 // exact test, and ties are broken by the stored list rank.  Results are identical by construction.
 // The hierarchy's leaves are single triangles or groups of two (three in the build for deep trees)
 // neighbours behind one box, which one step tests: a step's fixed cost is what limits the kernel.
+// In the build for deep trees, once a wavefront has only a handful of slots left, all its lanes scan ONE
+// slot's list together (k_main, "the wavefront scans ..."): the scan is an order-free reduction, and a ray
+// through a fan of thousands of slivers would otherwise walk it alone, one step after the other.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -108,12 +111,16 @@ constexpr int N_EVENTS = 22;
 constexpr int N_STATS = 11 + 2 * N_EVENTS; // 11..: per event, the steps in which some lane met it, and the lanes that did
 #elif defined(RT_DRAIN) // when the wavefronts start, find the work counter dry, and end (100 MHz clock): how a launch ramps up and drains
 constexpr int DRAIN_BINS = 300; // wavefronts by the time from dry to end, bins of 10 us
-constexpr int N_STATS = 11 + 8 + DRAIN_BINS + 8; // 11 min start, 12 max start, 13 min dry, 14 sum dry, 15 max dry, 16 sum end, 17 max end, 18 wavefronts; after the bins: steps and lanes per kind once the counter is dry
+constexpr int N_STATS = 11 + 8 + DRAIN_BINS + 8 + 6; // (+ 6: steps of each kind run for a wavefront's last slot alone; list scans taken over by the wavefront, their batches) // 11 min start, 12 max start, 13 min dry, 14 sum dry, 15 max dry, 16 sum end, 17 max end, 18 wavefronts; after the bins: steps and lanes per kind once the counter is dry
 #else
 constexpr int N_STATS = 11;
 #endif
 #ifndef RT_SMALL_LIST
 #define RT_SMALL_LIST 1
+#endif
+// The wavefront-wide list scan (see k_main, "one slot left"): 0 never, 1 in the build for deep trees, 2 in both builds.
+#ifndef RT_COOP
+#define RT_COOP 1
 #endif
 constexpr int SMALL_LIST = RT_SMALL_LIST; // own lists up to this length are tested directly, longer ones get a hierarchy
 constexpr int SPH_HIER_MIN = 16; // scenes with at least this many spheres get a hierarchy over them
@@ -220,6 +227,7 @@ struct DevScene {
     int n_sph;
     int ovf_depth;
     int n_slots;
+    int coop_reserve; // room the wavefront-wide list scan keeps free in its work list (4 x the deepest culling hierarchy + 8); 0: never scans that way
 };
 
 struct DevCamera {
@@ -679,8 +687,16 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
 #ifdef RT_DRAIN
     const unsigned long long dr_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long dr_dry = 0;
-    unsigned dr_steps[4] = {0, 0, 0, 0}, dr_lanes[4] = {0, 0, 0, 0};
+    unsigned dr_steps[4] = {0, 0, 0, 0}, dr_lanes[4] = {0, 0, 0, 0}, dr_lone[6] = {0, 0, 0, 0, 0, 0};
 #endif
+    constexpr bool COOP = !SPH && (RT_COOP == 2 || (RT_COOP == 1 && LDS_STACK >= 8));
+#ifndef RT_COOP_SLOTS
+#define RT_COOP_SLOTS 16
+#endif
+    constexpr int COOP_SLOTS = RT_COOP_SLOTS; // the most slots that may still be active when the wavefront scans one slot's list together
+    // items the wavefront-wide scan takes: single triangles (not the chains of short lists) and groups; inner records
+    auto coop_leaf = [](unsigned x) __attribute__((always_inline)) { const unsigned k = x >> 29; return k == 3u || (k == 2u && !(x & IT_CHAIN)); };
+    auto coop_inner = [](unsigned x) __attribute__((always_inline)) { return (x >> 29) == 1u; };
     for (;;) {
         RT_TICK(tk0);
         RT_MARK("pick");
@@ -691,7 +707,17 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         if (q2 > most) { most = q2; pick = K_TRI; }
         if (q3 > most) { most = q3; pick = K_SHADE; }
         if (most == 0) break; // every slot is done
-        const int nrun = most < WAVE ? most : WAVE;
+        int nrun = most < WAVE ? most : WAVE;
+        // A handful of slots left, and the next one is scanning an own list's hierarchy: a ray through a fan of thousands of
+        // slivers takes thousands of such steps one after the other while the other lanes idle (on the Lucy-class frame a
+        // fifth of the launch is a handful of such rays, four to a wavefront: a pixel's sub-pixels).  A list's scan is an
+        // order-free reduction -- the nearest accepted triangle, the lower list rank among equals, "was any accepted" --
+        // so the wavefront then scans that ONE slot's list together: see the step below.
+        bool coop = false;
+        if (COOP && S.coop_reserve > 0 && (pick == K_CULL || pick == K_TRI) && q0 + q1 + q2 + q3 <= COOP_SLOTS) {
+            const unsigned it0 = (unsigned)__builtin_amdgcn_readfirstlane((int)sQ[qindex(pick, most - 1)].y);
+            if (coop_leaf(it0) || coop_inner(it0)) { coop = true; nrun = 1; }
+        }
         const int rest = most - nrun;
         if (pick == K_NODE) q0 = rest; else if (pick == K_CULL) q1 = rest; else if (pick == K_TRI) q2 = rest; else q3 = rest;
         const bool run = lane < nrun;
@@ -709,6 +735,10 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         if (dr_dry != 0) {
 #pragma unroll
             for (int k = 0; k < 4; k++) if (pick == k) { dr_steps[k]++; dr_lanes[k] += (unsigned)nrun; }
+        }
+        if (most == 1 && q0 + q1 + q2 + q3 == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (pick == k) dr_lone[k]++;
         }
 #endif
 
@@ -751,6 +781,167 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         RT_TICK(tk1);
         RT_MARK("bodies");
 
+        if (COOP && coop) {
+            RT_MARK("coop");
+            // ---- the wavefront scans the rest of the slot's current list together.  Two work lists in LDS, leaves and inner
+            // records, in the parts of the scheduler's stacks that at most COOP_SLOTS entries per stack leave free.  Leaves
+            // first; a batch of inner records only as wide as leaves room for all its children plus S.coop_reserve words,
+            // below which the scan goes on one record at a time, depth first, which needs at most three words per level
+            // of the hierarchy.
+            const int slot_u = __builtin_amdgcn_readfirstlane(slot), sl_u = slot_u + wslot0;
+            const unsigned st_u = (unsigned)__builtin_amdgcn_readfirstlane((int)st), cur_u = (unsigned)__builtin_amdgcn_readfirstlane((int)cur);
+            int sp_u = __builtin_amdgcn_readfirstlane(sp);
+            const int slo_u = __builtin_amdgcn_readfirstlane(slo);
+            unsigned *const WT = (unsigned *)(sQ + 2 * wslot0) + 2 * COOP_SLOTS, *const WC = WT + 2 * SLOTS;
+            constexpr int CAP = 2 * SLOTS - 4 * COOP_SLOTS; // words of each list
+            static_assert(CAP >= 2 * 64 + 16, "the largest reserve (rt_prepare_scene) and a record's children fit");
+            int nT = 0, nC = 0;
+            int k_steps = 0, k_lanes = 0, k_done = 0; // (work counters of the scan, added to the wavefront's after it)
+            auto put = [&](unsigned x) __attribute__((always_inline)) {
+                if (coop_leaf(x)) { if (lane == 0) WT[nT] = x; nT++; }
+                else { if (lane == 0) WC[nC] = x; nC++; }
+            };
+            put(cur_u);
+            // what the ring holds of the same list on top of anything else comes along (levels in HBM stay: the refill brings them)
+            while (sp_u > slo_u) {
+                const unsigned x = (unsigned)__builtin_amdgcn_readfirstlane((int)stk[(sp_u - 1) & (LDS_STACK - 1)][sl_u]);
+                if (!(coop_leaf(x) || coop_inner(x)) || nT >= 16 || nC >= 16) break;
+                put(x);
+                sp_u--;
+            }
+            const SlotWords lu = {(char *)S.lstate, (gslot0 + (unsigned)slot_u) * 8u};
+            const double2 a = sA[sl_u], b = sB[sl_u], c = sC[sl_u];
+            const d3 o = mk(a.x, a.y, b.x), d = mk(lu[LS_V * lss], lu[(LS_V + 1) * lss], lu[(LS_V + 2) * lss]);
+            const float mg = exp_up_get(sM[sl_u]);
+            const float tlim = (st_u & ST_FLAG) ? half_up_get(sT[sl_u]) * 1.000001f : INFINITY; // (as the cull step: once the frame has a hit)
+            // per lane: the best of the triangles this lane tested -- smallest distance, lower list rank among equals
+            double ct = 1e20;
+            unsigned cha = 0;
+            int crank = 0x7FFFFFFF;
+            bool chit = false;
+            while (nT + nC > 0) {
+                k_steps++;
+                if (nT > 0) { // ---- a batch of leaves: the exact tests (kdtree.cpp:105)
+                    const int m = nT < WAVE ? nT : WAVE;
+                    nT -= m;
+                    k_lanes += m;
+                    const bool act = lane < m;
+                    const unsigned x = act ? WT[nT + lane] : 0u;
+                    const bool grp = (x >> 29) == 3u;
+                    const unsigned gn = !act ? 0u : grp ? ((x >> 26) & 3u) + 2u : 1u;
+                    if (act) {
+                        const double2 *p = (const double2 *)pool_at(S.pool, grp ? S.g_tri + 5u * (x & GROUP_POS) : (x & IDX28));
+#pragma unroll
+                        for (int k = 0; k < GROUP; k++) {
+                            if (gn > (unsigned)k) {
+                                const double2 *r = p + 5 * k;
+                                const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+                                const double t = tri_hit(mk(r0.x, r0.y, r1.x), mk(r1.y, r2.x, r2.y), mk(r3.x, r3.y, r4.x), o, d);
+                                const long long w = __double_as_longlong(r4.y);
+                                if (t > EPS) {
+                                    const int rk = (int)(w >> 32);
+                                    if (t < ct || (t == ct && t < 1e20 && rk < crank)) { ct = t; cha = (unsigned)w & ~TRI_LAST; crank = rk; }
+                                    if (t < 1e10) chit = true;
+                                }
+                            }
+                        }
+                    }
+                    {
+                        int tested = 0;
+#pragma unroll
+                        for (int k = 0; k < GROUP; k++) tested += (int)__popcll(__ballot(gn > (unsigned)k));
+                        k_done += tested;
+                    }
+                } else { // ---- a batch of inner records: four child boxes each, as in the cull step
+                    int m = (CAP - nC - S.coop_reserve) / 4;
+                    m = m < 1 ? 1 : m;
+                    m = m < nC ? m : nC;
+                    m = m < CAP / 4 ? m : CAP / 4; // (no leaf is waiting: all children of the batch fit the leaves' list)
+                    m = m < WAVE ? m : WAVE;
+                    nC -= m;
+                    k_lanes += m;
+                    const bool act = lane < m;
+                    const unsigned x = act ? WC[nC + lane] : 0u;
+                    bool hit[4] = {false, false, false, false};
+                    unsigned item[4] = {0u, 0u, 0u, 0u};
+                    if (act) {
+                        const uint4 *p = (const uint4 *)pool_at(S.pool, x & IDX28);
+                        const uint4 r0 = p[0], r1 = p[1], r2 = p[2], it = p[3];
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        const float sf[3] = {(float)a.x, (float)a.y, (float)b.x}, ivf[3] = {cull_inv((float)b.y), cull_inv((float)c.x), cull_inv((float)c.y)};
+                        const float mt = (mg + S.fslack + 9.6e-7f * (fabsf(sf[0]) + fabsf(sf[1]) + fabsf(sf[2]))) * 1.000001f;
+                        const float base[3] = {__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)};
+                        const float step[3] = {__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)};
+                        const unsigned qw[6] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                        item[0] = it.x; item[1] = it.y; item[2] = it.z; item[3] = it.w;
+                        f2 ka[3], kb[3];
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            const float a1 = step[i] * ivf[i];
+                            ka[i] = (f2){a1, a1};
+                            kb[i] = (f2){(base[i] - (sf[i] + mt)) * ivf[i], (base[i] - (sf[i] - mt)) * ivf[i]};
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            float ta[3], tb[3];
+#pragma unroll
+                            for (int i = 0; i < 3; i++) {
+                                const int bi = (k * 3 + i) * 2;
+                                const unsigned wd = qw[bi >> 2];
+                                const f2 qf = (bi & 2) ? (f2){(float)((wd >> 16) & 0xFFu), (float)(wd >> 24)} : (f2){(float)(wd & 0xFFu), (float)((wd >> 8) & 0xFFu)};
+                                const f2 t = __builtin_elementwise_fma(qf, ka[i], kb[i]);
+                                ta[i] = fminf(t.x, t.y);
+                                tb[i] = fmaxf(t.x, t.y);
+                            }
+                            const float tmin = fmaxf(fmaxf(ta[0], ta[1]), fmaxf(ta[2], 0.0f)), tmax = fminf(fminf(tb[0], tb[1]), fminf(tb[2], tlim));
+                            hit[k] = (tmin * 0.999999f <= tmax) & (item[k] != 0);
+                        }
+                        l_culls += 1u;
+                    }
+                    // the children that are met join the work list, each kind on its side
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool lf = hit[k] && coop_leaf(item[k]), in = hit[k] && !coop_leaf(item[k]); // (a hierarchy's children: triangle, group or record)
+                        const unsigned long long ml = __ballot(lf), mi = __ballot(in);
+                        if (lf) WT[nT + (int)__popcll(ml & lane_lt)] = item[k];
+                        if (in) WC[nC + (int)__popcll(mi & lane_lt)] = item[k];
+                        nT += (int)__popcll(ml);
+                        nC += (int)__popcll(mi);
+                    }
+                }
+            }
+#ifdef RT_DRAIN
+            dr_lone[4]++; dr_lone[5] += (unsigned)__builtin_amdgcn_readfirstlane(k_steps);
+#endif
+            RT_SCOUNT(c_iters, __builtin_amdgcn_readfirstlane(k_steps)); RT_SCOUNT(c_lanes, __builtin_amdgcn_readfirstlane(k_lanes)); RT_SCOUNT(c_done, __builtin_amdgcn_readfirstlane(k_done));
+            // ---- the wavefront's best: smallest distance, then lower rank; against what the slot holds: strict < keeps the
+            // earlier of two equal distances -- inside one list the lower rank, across lists the list visited first
+            double bt = ct;
+            for (int off = 32; off > 0; off >>= 1) { const double v = __shfl_xor(bt, off, 64); bt = v < bt ? v : bt; }
+            int br = ct == bt ? crank : 0x7FFFFFFF;
+            for (int off = 32; off > 0; off >>= 1) { const int v = __shfl_xor(br, off, 64); br = v < br ? v : br; }
+            const unsigned long long mw = __ballot(ct == bt && crank == br);
+            const unsigned bha = (unsigned)__builtin_amdgcn_readlane((int)cha, mw ? __ffsll((long long)mw) - 1 : 0);
+            const bool any = __ballot(chit) != 0;
+            if (run) {
+                const double best_t = ls[LS_BT * lss];
+                if (bt < 1e20) {
+                    bool better = bt < best_t;
+                    if (__builtin_expect(bt == best_t, 0)) {
+                        const uint2 lb = S.tlist[((const unsigned *)&ls[LS_HA * lss])[0]], lc = S.tlist[bha];
+                        better = lb.x == lc.x && br < (int)lb.y;
+                    }
+                    if (better) {
+                        ls[LS_BT * lss] = bt;
+                        sT[sl] = half_up_put((float)bt * 1.000001f);
+                        ls[LS_HA * lss] = __longlong_as_double((long long)(unsigned long long)bha);
+                    }
+                }
+                if (any) st |= ST_FLAG;
+                sp = sp_u;
+                want_pop = true;
+            }
+        } else
         if (pick == K_NODE) {
             RT_MARK("node");
             const bool refill = run && cur == IT_REFILL;
@@ -1616,6 +1807,7 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         atomicAdd(gstats + 16, dr_end - dr_start); atomicMax(gstats + 17, dr_end); atomicAdd(gstats + 18, 1ull);
         { const unsigned long long b = (dr_end - dr_dry) / 1000ull; atomicAdd(gstats + 19 + (b < DRAIN_BINS ? b : DRAIN_BINS - 1), 1ull); }
         for (int k = 0; k < 4; k++) { atomicAdd(gstats + 19 + DRAIN_BINS + k, (unsigned long long)dr_steps[k]); atomicAdd(gstats + 23 + DRAIN_BINS + k, (unsigned long long)dr_lanes[k]); }
+        for (int k = 0; k < 6; k++) atomicAdd(gstats + 27 + DRAIN_BINS + k, (unsigned long long)dr_lone[k]);
     }
 #endif
     // ---- work counters
@@ -2629,6 +2821,11 @@ int rt_prepare_scene(const rt_scene_desc *D, rt_prepared **out) {
         if (ss[i].lig[0] != 0 || ss[i].lig[1] != 0 || ss[i].lig[2] != 0) P->lights.push_back(i);
     P->tree_depth = tree_depth;
     P->cull_depth = cull_depth;
+    { // the wavefront-wide list scan's reserve (k_main): three words per level of the deepest hierarchy, generously
+        const char *e = getenv("RT_HIP_COOP"); // tuning / test knob: 0 = every list is scanned by its slot alone
+        const int reserve = 4 * cull_depth + 8;
+        P->d.coop_reserve = (e && atoi(e) == 0) || reserve > 2 * 64 ? 0 : reserve;
+    }
     P->deep = deep;
     P->has_tex = n_textri != 0;
     P->cold.n_lights = (int)P->lights.size();
@@ -2900,7 +3097,8 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
         fprintf(stderr, "\n[drain] after dry, per wavefront:");
         { static const char *kn[4] = {"node", "cull", "tri", "shade"};
           for (int k = 0; k < 4; k++) fprintf(stderr, " %s %.1f steps x %.1f lanes", kn[k], (double)h[19 + DRAIN_BINS + k] / w, h[19 + DRAIN_BINS + k] ? (double)h[23 + DRAIN_BINS + k] / h[19 + DRAIN_BINS + k] : 0.0); }
-        fprintf(stderr, "\n");
+        fprintf(stderr, "\n[drain] steps for a wavefront's last slot alone, all wavefronts: node %llu cull %llu tri %llu shade %llu; list scans by the wavefront %llu in %llu batches\n",
+                h[27 + DRAIN_BINS], h[28 + DRAIN_BINS], h[29 + DRAIN_BINS], h[30 + DRAIN_BINS], h[31 + DRAIN_BINS], h[32 + DRAIN_BINS]);
     }
 #endif
 #ifdef RT_PROFILE

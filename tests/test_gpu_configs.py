@@ -97,6 +97,48 @@ def test_naturally_deep_tree_runs_the_deep_tree_kernel_build(ra, po):
         del os.environ["RT_HIP_DEEP_TREE"]
 
 
+def test_wavefront_wide_list_scan_of_a_sliver_fan(ra, po):
+    """The deep-tree build lets the whole wavefront scan ONE slot's own list once only a handful of slots are left
+    (a ray through a fan of thousands of slivers would otherwise take thousands of steps alone).  A sphere of 8 bands
+    x 3 000 segments has two such fans; rays straight down its axis meet both.  Same ids, distances and reference
+    work counters as the oracle, the same as with the scan switched off, and a frame looking down the axis."""
+    import os
+    from raytrace_amd import scenes
+    body = scenes.blob((50, 30, 80), 20.0, 8, 3000, seed=7, amp=0.2)
+    floor = scenes.grid((-100, 0, -100), (0, 0, 400), (400, 0, 0), 2, 2)
+    sc = {"name": "fan", "meshes": [scenes._mesh(floor, (.6, .6, .6), scenes.DIFF), scenes._mesh(body, (.75, .7, .6), scenes.DIFF)],
+          "spheres": [scenes._sphere(40, (60, 150, 140), (12, 12, 12), (0, 0, 0), scenes.DIFF)],
+          "camera": {"o": np.array([50.3, 230.0, 80.2]), "d": np.array([0.001, -1.0, 0.002])}, "sizex": 24, "sizey": 32}
+    hs = ra.HostScene(sc)
+    orc = po.OracleScene(sc)
+    rs = np.random.RandomState(5)
+    n = 400
+    o = np.stack([50 + rs.normal(0, 0.02, n), np.full(n, 120.0), 80 + rs.normal(0, 0.02, n)], 1)
+    d = np.stack([rs.normal(0, 1e-4, n), np.full(n, -1.0), rs.normal(0, 1e-4, n)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([np.concatenate([o, d], 1), random_rays(9, 2000, np.array([50, 40, 80.0]), 60.0)])
+    assert "RT_HIP_DEEP_TREE" not in os.environ and "RT_HIP_COOP" not in os.environ
+    os.environ["RT_HIP_DEEP_TREE"] = "0"
+    try:
+        dev = ra.DeviceScene(hs, 0)
+        os.environ["RT_HIP_COOP"] = "0"
+        dev_off = ra.DeviceScene(hs, 0)
+    finally:
+        del os.environ["RT_HIP_DEEP_TREE"]
+        os.environ.pop("RT_HIP_COOP", None)
+    a = _same_queries(dev, orc, rays)
+    b = _same_queries(dev_off, orc, rays)
+    assert (a[0][:n] >= 0).all() and a[4]["tri_tests"] > 1000 * n  # the reference tests thousands of slivers per ray
+    # the scan ran: far fewer scheduler steps than with one slot working through the fan alone
+    assert a[4]["sched_steps"] < 0.75 * b[4]["sched_steps"], (a[4]["sched_steps"], b[4]["sched_steps"])
+    kw = dict(samps=1, rr_depth=3, rr_mode=0, split_depth=2, hard_depth=64, jitter=1, seed=4)
+    rgb, pid, _ = _same_frame(ra, po, dev, orc, sc, 24, 32, kw)
+    rgb0, pid0, _ = _same_frame(ra, po, dev_off, orc, sc, 24, 32, kw)
+    assert np.array_equal(pid, pid0) and np.array_equal(rgb, rgb0)
+    dev.close()
+    dev_off.close()
+
+
 def _chain_desc(ra, depth):
     """A degenerate but valid description: `depth` nodes, each the left child of the one before, one
     triangle on the last node's own list."""
