@@ -715,8 +715,20 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         // so the wavefront then scans that ONE slot's list together: see the step below.
         bool coop = false;
         if (COOP && S.coop_reserve > 0 && (pick == K_CULL || pick == K_TRI) && q0 + q1 + q2 + q3 <= COOP_SLOTS) {
-            const unsigned it0 = (unsigned)__builtin_amdgcn_readfirstlane((int)sQ[qindex(pick, most - 1)].y);
-            if (coop_leaf(it0) || coop_inner(it0)) { coop = true; nrun = 1; }
+            // (only a scan that is evidently wide: the slot's item and the three newest levels of its stack are all work of
+            // the same list -- a scan of a few records is served faster by ordinary steps, which serve all slots at once)
+            const uint2 e0 = sQ[qindex(pick, most - 1)];
+            const unsigned it0 = (unsigned)__builtin_amdgcn_readfirstlane((int)e0.y), f0 = (unsigned)__builtin_amdgcn_readfirstlane((int)e0.x);
+            const int sl0 = (int)(f0 & 0xFFu) + wslot0, sp0 = (int)((f0 >> 8) & ST_SP), slo0 = (int)((f0 >> (8 + ST_LO)) & 0xFFu);
+            if ((coop_leaf(it0) || coop_inner(it0)) && sp0 - slo0 >= 3) {
+                bool wide = true;
+#pragma unroll
+                for (int k = 1; k <= 3; k++) {
+                    const unsigned x = (unsigned)__builtin_amdgcn_readfirstlane((int)stk[(sp0 - k) & (LDS_STACK - 1)][sl0]);
+                    wide = wide && (coop_leaf(x) || coop_inner(x));
+                }
+                if (wide) { coop = true; nrun = 1; }
+            }
         }
         const int rest = most - nrun;
         if (pick == K_NODE) q0 = rest; else if (pick == K_CULL) q1 = rest; else if (pick == K_TRI) q2 = rest; else q3 = rest;
