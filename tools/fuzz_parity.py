@@ -31,6 +31,12 @@ def main():
     cases.append(("lamps", scenes.lamp_room(), np.array([50, 40, 80.0]), 60.0))
     cases.append(("texroom", scenes.textured_room(), np.array([20, 40, 40.0]), 60.0))
     cases.append(("deep", scenes.deep_tree(), np.array([300, 300, 300.0]), 500.0))
+    # a sphere of 8 bands x 2 000 segments: two fans of 2 000 slivers, huge own lists (the wavefront-wide list scan of the deep-tree build)
+    fan = {"name": "fan", "meshes": [scenes._mesh(scenes.blob((50, 30, 80), 20.0, 8, 2000, seed=7, amp=0.2), (.75, .7, .6), scenes.DIFF),
+                                     scenes._mesh(scenes.grid((-100, 0, -100), (0, 0, 400), (400, 0, 0), 2, 2), (.6, .6, .6), scenes.DIFF)],
+           "spheres": [scenes._sphere(40, (60, 150, 140), (12, 12, 12), (0, 0, 0), scenes.DIFF)],
+           "camera": {"o": np.array([50.3, 230.0, 80.2]), "d": np.array([0.001, -1.0, 0.002])}, "sizex": 48, "sizey": 64}
+    cases.append(("fan", fan, np.array([50, 45, 80.0]), 30.0))
     for name, sc, ctr, spr in cases:
         hs = ra.HostScene(sc)
         dev = ra.DeviceScene(hs, 0)
