@@ -139,7 +139,10 @@ typedef struct rt_stats {
     uint64_t tri_tests;   /* Polygon::intersect in check_node  (kdtree.cpp:105): what the reference would run */
     uint64_t sph_tests;   /* Sphere::intersect                 (sphere.cpp:8) */
     uint64_t tri_shades;  /* rays whose chosen hit is a triangle (raytrace.cpp:58-67) */
-    /* what the kernel actually executed (long own lists are culled conservatively, results unchanged) */
+    /* what the kernel actually executed (long own lists are culled conservatively, results unchanged).  These two and
+     * the scheduler's figures below depend on which boxes the best hit so far lets the kernel drop, i.e. on the order
+     * in which a list is scanned: in the kernel build for deep trees, where a wavefront's last slots may be scanned by
+     * all its lanes together, they can differ by a few from run to run.  The five counters above never do. */
     uint64_t tri_tests_done; /* exact triangle tests performed */
     uint64_t cull_tests;     /* culling records (four boxes each) tested */
     /* the wavefront scheduler: steps executed and lanes that took part in them
