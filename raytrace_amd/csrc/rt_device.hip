@@ -582,6 +582,13 @@ __device__ __forceinline__ unsigned char exp_up_put(float x) { return (unsigned 
 __device__ __forceinline__ float exp_up_get(unsigned char e) { return __uint_as_float((unsigned)e << 23); }
 __device__ __forceinline__ float cull_inv(float x) { return fminf(fmaxf(x, -1e30f), 1e30f); }
 
+#ifdef RT_DRAIN
+// per wavefront of the last launch: time from dry to end (100 MHz ticks), steps of the four kinds after dry, steps for its last
+// slot alone, list scans taken over by the wavefront and their batches
+constexpr int DRAIN_WAVES = 4096;
+static __device__ unsigned dr_waves[DRAIN_WAVES][8];
+#endif
+
 // SPH = true: the scene has a sphere hierarchy (a second instance, so that scenes without one do not pay for it).
 // SLOTS, LDS_STACK, WPG, GROUP: see KernelCfg.
 // FEAT selects what the shade step can do beyond the reference's untextured integrator (instances of their own, like
@@ -1820,6 +1827,15 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         { const unsigned long long b = (dr_end - dr_dry) / 1000ull; atomicAdd(gstats + 19 + (b < DRAIN_BINS ? b : DRAIN_BINS - 1), 1ull); }
         for (int k = 0; k < 4; k++) { atomicAdd(gstats + 19 + DRAIN_BINS + k, (unsigned long long)dr_steps[k]); atomicAdd(gstats + 23 + DRAIN_BINS + k, (unsigned long long)dr_lanes[k]); }
         for (int k = 0; k < 6; k++) atomicAdd(gstats + 27 + DRAIN_BINS + k, (unsigned long long)dr_lone[k]);
+        {
+            const unsigned wid = blockIdx.x * WPG + wv;
+            if (wid < (unsigned)DRAIN_WAVES) {
+                unsigned *r = dr_waves[wid];
+                r[0] = (unsigned)(dr_end - dr_dry);
+                for (int k = 0; k < 4; k++) r[1 + k] = dr_steps[k];
+                r[5] = dr_lone[0] + dr_lone[1] + dr_lone[2] + dr_lone[3]; r[6] = dr_lone[4]; r[7] = dr_lone[5];
+            }
+        }
     }
 #endif
     // ---- work counters
@@ -3109,6 +3125,19 @@ int rt_get_stats(rt_scene *s, rt_stats *stats) {
         fprintf(stderr, "\n[drain] after dry, per wavefront:");
         { static const char *kn[4] = {"node", "cull", "tri", "shade"};
           for (int k = 0; k < 4; k++) fprintf(stderr, " %s %.1f steps x %.1f lanes", kn[k], (double)h[19 + DRAIN_BINS + k] / w, h[19 + DRAIN_BINS + k] ? (double)h[23 + DRAIN_BINS + k] / h[19 + DRAIN_BINS + k] : 0.0); }
+        {
+            static unsigned hw[DRAIN_WAVES][8];
+            if (hipMemcpyFromSymbol(hw, HIP_SYMBOL(dr_waves), sizeof(hw)) == hipSuccess) {
+                std::vector<int> idx(DRAIN_WAVES);
+                for (int i = 0; i < DRAIN_WAVES; i++) idx[i] = i;
+                std::partial_sort(idx.begin(), idx.begin() + 6, idx.end(), [&](int a, int b) { return hw[a][0] > hw[b][0]; });
+                for (int k = 0; k < 6; k++) {
+                    const unsigned *r = hw[idx[k]];
+                    fprintf(stderr, "\n[drain]   wavefront %4d: %7.1f us from dry to end; after dry node %u cull %u tri %u shade %u steps; %u steps for its last slot alone; %u list scans in %u batches",
+                            idx[k], r[0] * 0.01, r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+                }
+            }
+        }
         fprintf(stderr, "\n[drain] steps for a wavefront's last slot alone, all wavefronts: node %llu cull %llu tri %llu shade %llu; list scans by the wavefront %llu in %llu batches\n",
                 h[27 + DRAIN_BINS], h[28 + DRAIN_BINS], h[29 + DRAIN_BINS], h[30 + DRAIN_BINS], h[31 + DRAIN_BINS], h[32 + DRAIN_BINS]);
     }
