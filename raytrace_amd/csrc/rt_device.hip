@@ -700,6 +700,10 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
 #ifndef RT_COOP_SLOTS
 #define RT_COOP_SLOTS 16
 #endif
+#ifndef RT_COOP_WIDE
+#define RT_COOP_WIDE 2
+#endif
+    constexpr int COOP_WIDE = RT_COOP_WIDE; // stack levels below the slot's item that must be work of the same list for its scan to count as wide
     constexpr int COOP_SLOTS = RT_COOP_SLOTS; // the most slots that may still be active when the wavefront scans one slot's list together
     // items the wavefront-wide scan takes: single triangles (not the chains of short lists) and groups; inner records
     auto coop_leaf = [](unsigned x) __attribute__((always_inline)) { const unsigned k = x >> 29; return k == 3u || (k == 2u && !(x & IT_CHAIN)); };
@@ -722,15 +726,17 @@ __global__ __launch_bounds__(WAVE * WPG, RT_MIN_WAVES) __attribute__((aligned(RT
         // so the wavefront then scans that ONE slot's list together: see the step below.
         bool coop = false;
         if (COOP && S.coop_reserve > 0 && (pick == K_CULL || pick == K_TRI) && q0 + q1 + q2 + q3 <= COOP_SLOTS) {
-            // (only a scan that is evidently wide: the slot's item and the three newest levels of its stack are all work of
-            // the same list -- a scan of a few records is served faster by ordinary steps, which serve all slots at once)
+            // (only a scan that has several items to offer: the slot's item and the COOP_WIDE newest levels of its stack are
+            // work of the same list; a lone triangle or record is served faster by an ordinary step, which serves all slots
+            // at once.  On this build, Mrays/s with one / two / three levels against no such scan: Lucy-class 4K 1 995 / 1 973 /
+            // 1 956 against 1 673; a scene of short lists, the Cornell demo, 3 206 / 3 414 / 3 457 against 3 511)
             const uint2 e0 = sQ[qindex(pick, most - 1)];
             const unsigned it0 = (unsigned)__builtin_amdgcn_readfirstlane((int)e0.y), f0 = (unsigned)__builtin_amdgcn_readfirstlane((int)e0.x);
             const int sl0 = (int)(f0 & 0xFFu) + wslot0, sp0 = (int)((f0 >> 8) & ST_SP), slo0 = (int)((f0 >> (8 + ST_LO)) & 0xFFu);
-            if ((coop_leaf(it0) || coop_inner(it0)) && sp0 - slo0 >= 3) {
+            if ((coop_leaf(it0) || coop_inner(it0)) && sp0 - slo0 >= COOP_WIDE) {
                 bool wide = true;
 #pragma unroll
-                for (int k = 1; k <= 3; k++) {
+                for (int k = 1; k <= COOP_WIDE; k++) {
                     const unsigned x = (unsigned)__builtin_amdgcn_readfirstlane((int)stk[(sp0 - k) & (LDS_STACK - 1)][sl0]);
                     wide = wide && (coop_leaf(x) || coop_inner(x));
                 }
