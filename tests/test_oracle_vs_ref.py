@@ -1,5 +1,6 @@
 """The oracle against the reference's own object code (oracle/_ref), live, on inputs beyond the
 committed fixtures.  Skipped where _ref was not built (it needs the reference checkout)."""
+import os
 import numpy as np
 import pytest
 
@@ -143,14 +144,25 @@ def test_reference_side_binding_produces_the_host_librarys_description(ref, ra):
 
 def test_host_builder_equals_the_reference_builder_at_scale(ref, ra):
     """kdtree.cpp:6-96 against the index-based builder of librt_host.so on four million triangles (a 27-level tree of
-    half a million nodes): boxes, splits, axes, children and own lists bit for bit.  (The same comparison at the
-    Lucy-class size, 28 055 742 triangles / 30 levels / 3.7 M nodes, also holds; it needs 34 GB and a minute for the
-    reference's builder, so it is not part of the suite.)"""
+    half a million nodes): boxes, splits, axes, children and own lists bit for bit."""
     from raytrace_amd import scenes
     sc = scenes.bunny_class(4_000_000)
     a = ra.HostScene(sc).tree_arrays()
     b = ref.RefScene(sc).tree_dump()
     assert a["depth"] >= 27 and len(a["axis"]) > 500000
+    for k in b:
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.skipif(not os.environ.get("RT_TEST_LUCY_BUILD"), reason="34 GB and some minutes: set RT_TEST_LUCY_BUILD=1")
+def test_host_builder_equals_the_reference_builder_at_lucy_scale(ref, ra):
+    """The same comparison on the timed Lucy-class scene itself, 28 055 742 triangles (a tree of 30 levels): opt-in,
+    because the reference's builder needs 34 GB for it."""
+    from raytrace_amd import scenes
+    sc = scenes.lucy_class(28055742, 24, 40)
+    a = ra.HostScene(sc).tree_arrays()
+    b = ref.RefScene(sc).tree_dump()
+    assert a["depth"] >= 28 and len(a["axis"]) > 3_000_000
     for k in b:
         assert np.array_equal(a[k], b[k]), k
 
